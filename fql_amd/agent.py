@@ -1,0 +1,369 @@
+"""Host-side mirror of the reference's FQLAgent (agents/fql.py:15-246) over the C ABI.
+
+Same method names, keyword names and return shapes as the reference so its call sites keep working:
+
+    agent = FQLAgent.create(seed, ex_observations, ex_actions, config)      # main.py:160
+    agent, info = agent.update(batch)                                         # main.py:216
+    actions = agent.sample_actions(observations=ob, temperature=1, seed=key)  # main.py:225
+    loss, info = agent.total_loss(val_batch, grad_params=None)                # main.py:284
+    actions = agent.compute_flow_actions(observations, noises)                # agents/fql.py:155
+
+The reference is functional (update returns a NEW agent, callers rebind); here the engine owns the
+state in HBM, update mutates it and returns ``self`` -- compatible with every reference call site.
+All compute happens in libfql_amd.so (HIP, gfx950); there is no Python/torch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Dict, Optional
+
+import numpy as np
+
+from . import _cabi
+from .config import ConfigDict, get_config
+
+INFO_KEYS = (
+    'critic/critic_loss', 'critic/q_mean', 'critic/q_max', 'critic/q_min',
+    'actor/actor_loss', 'actor/bc_flow_loss', 'actor/distill_loss', 'actor/q_loss',
+    'actor/q', 'actor/mse', 'grad/max', 'grad/min', 'grad/norm',
+)
+NOISE_KEYS = ('eps1', 'x0', 't', 'z', 'eps2')
+BATCH_KEYS = ('observations', 'actions', 'rewards', 'masks', 'next_observations')
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _seed_to_u64(seed) -> int:
+    """Accept what reference call sites pass as `seed`: None, int, or a JAX-style uint32[2] key."""
+    if seed is None:
+        return 0
+    a = np.asarray(seed)
+    if a.ndim == 0:
+        return int(a) & 0xFFFFFFFFFFFFFFFF
+    a = a.astype(np.uint64).reshape(-1)
+    v = 0
+    for x in a[:2]:
+        v = ((v << 32) | (int(x) & 0xFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF
+    return v
+
+
+class _Arg:
+    """fp32 contiguous view of a user array + the pointer handed to the C ABI (device or host)."""
+
+    def __init__(self, x, shape=None):
+        self.keep = None
+        if x is None:
+            self.ptr = None
+            return
+        if hasattr(x, 'data_ptr'):  # torch tensor (cuda or cpu)
+            torch = _torch()
+            t = x.detach()
+            if t.dtype != torch.float32:
+                t = t.float()
+            t = t.contiguous()
+            if shape is not None and int(np.prod(shape)) != t.numel():
+                raise ValueError(f'expected {int(np.prod(shape))} elements, got shape {tuple(t.shape)}')
+            self.keep = t
+            self.ptr = t.data_ptr()
+        else:
+            a = np.ascontiguousarray(np.asarray(x), dtype=np.float32)
+            if shape is not None and int(np.prod(shape)) != a.size:
+                raise ValueError(f'expected {int(np.prod(shape))} elements, got shape {a.shape}')
+            self.keep = a
+            self.ptr = a.ctypes.data
+
+
+class FQLAgent:
+    """Flow Q-learning agent backed by the MI355X step engine."""
+
+    def __init__(self, handle, config, seed):
+        self._lib = _cabi.load()
+        self._h = handle
+        self.config = config
+        self._seed = seed
+        self._keep = []
+        self._sample_calls = 0
+
+    # -- construction ---------------------------------------------------------------------
+    @classmethod
+    def create(cls, seed, ex_observations, ex_actions, config):
+        """agents/fql.py:173-246.  `config`: dict-like with the keys of get_config()."""
+        lib = _cabi.load()
+        cfg = get_config()
+        cfg.update(dict(config))
+        if cfg.get('encoder') is not None:
+            raise NotImplementedError('visual encoders (impala_small) are not on the built path yet (SURVEY.md 8f N1)')
+        ex_observations = np.asarray(ex_observations) if not hasattr(ex_observations, 'shape') else ex_observations
+        ob_dims = tuple(ex_observations.shape[1:])
+        if len(ob_dims) != 1:
+            raise ValueError(f'state-based observations expected, got ob_dims={ob_dims}')
+        action_dim = int(ex_actions.shape[-1])
+        c = _cabi.FqlConfig()
+        lib.fql_default_config(C.byref(c))
+        c.obs_dim, c.act_dim = int(ob_dims[0]), action_dim
+        ah, vh = tuple(cfg['actor_hidden_dims']), tuple(cfg['value_hidden_dims'])
+        if len(ah) > _cabi.FQL_MAX_HIDDEN or len(vh) > _cabi.FQL_MAX_HIDDEN:
+            raise ValueError('too many hidden layers')
+        c.num_actor_hidden, c.num_value_hidden = len(ah), len(vh)
+        for i, v in enumerate(ah):
+            c.actor_hidden[i] = int(v)
+        for i, v in enumerate(vh):
+            c.value_hidden[i] = int(v)
+        c.layer_norm, c.actor_layer_norm = int(bool(cfg['layer_norm'])), int(bool(cfg['actor_layer_norm']))
+        c.lr, c.discount, c.tau, c.alpha = float(cfg['lr']), float(cfg['discount']), float(cfg['tau']), float(cfg['alpha'])
+        if cfg['q_agg'] not in ('mean', 'min'):
+            raise ValueError(f"q_agg must be 'mean' or 'min', got {cfg['q_agg']!r}")
+        c.q_agg = 1 if cfg['q_agg'] == 'min' else 0
+        c.flow_steps = int(cfg['flow_steps'])
+        c.normalize_q_loss = int(bool(cfg['normalize_q_loss']))
+        c.batch_size = int(cfg['batch_size'])
+        h = C.c_void_p()
+        rc = lib.fql_create(C.byref(c), int(seed) & 0xFFFFFFFFFFFFFFFF, C.byref(h))
+        _cabi.check(lib, None, rc)
+        cfg['ob_dims'] = ob_dims
+        cfg['action_dim'] = action_dim
+        return cls(h, cfg, int(seed))
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.fql_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ----------------------------------------------------------------------------
+    def _check(self, rc):
+        _cabi.check(self._lib, self._h, rc)
+
+    @staticmethod
+    def _stream(args):
+        """Run on torch's current stream when any argument lives on the GPU (keeps torch's caching
+        allocator and the engine stream-ordered); otherwise the engine's own stream (NULL)."""
+        for a in args:
+            k = getattr(a, 'keep', None)
+            if k is not None and hasattr(k, 'is_cuda') and k.is_cuda:
+                return _torch().cuda.current_stream().cuda_stream
+        return None
+
+    def _batch_args(self, batch):
+        B = int(np.shape(batch['actions'])[0]) if not hasattr(batch['actions'], 'shape') else int(batch['actions'].shape[0])
+        od, ad = self.config['ob_dims'][0], self.config['action_dim']
+        shapes = {'observations': (B, od), 'actions': (B, ad), 'rewards': (B,), 'masks': (B,), 'next_observations': (B, od)}
+        for k in BATCH_KEYS:
+            if k not in batch:
+                raise KeyError(f'batch is missing {k!r}')
+        return B, [_Arg(batch[k], shapes[k]) for k in BATCH_KEYS]
+
+    def _noise_args(self, noise, B):
+        if noise is None:
+            return None, []
+        ad = self.config['action_dim']
+        shapes = {'eps1': (B, ad), 'x0': (B, ad), 't': (B,), 'z': (B, ad), 'eps2': (B, ad)}
+        args = [_Arg(noise.get(k), shapes[k]) for k in NOISE_KEYS]
+        nz = _cabi.FqlNoise(*[a.ptr for a in args])
+        return nz, args
+
+    def _ensure_batch(self, B):
+        if B != self.config['batch_size']:
+            self._check(self._lib.fql_set_batch_size(self._h, B))
+            self.config['batch_size'] = B
+
+    # -- reference API ----------------------------------------------------------------------
+    def update(self, batch, noise: Optional[Dict[str, Any]] = None, want_info: bool = True):
+        """agents/fql.py:122-133.  Returns (agent, info).  `noise` (optional) supplies the five random
+        tensors explicitly (parity runs); by default they come from the engine's device RNG."""
+        B, args = self._batch_args(batch)
+        self._ensure_batch(B)
+        nz, nargs = self._noise_args(noise, B)
+        stream = self._stream(args + nargs)
+        self._check(self._lib.fql_update(self._h, *[a.ptr for a in args], B, C.byref(nz) if nz else None, None, stream))
+        self._keep = (args, nargs)
+        return self, (self.read_info() if want_info else None)
+
+    def read_info(self) -> Dict[str, float]:
+        """The 13 info scalars of the last update (blocks until that update has run)."""
+        buf = (C.c_float * _cabi.FQL_NUM_INFO)()
+        self._check(self._lib.fql_read_info(self._h, buf))
+        return {k: float(buf[i]) for i, k in enumerate(INFO_KEYS)}
+
+    def total_loss(self, batch, grad_params=None, rng=None, noise: Optional[Dict[str, Any]] = None):
+        """agents/fql.py:94-111 with grad_params=None (the validation probe, main.py:284)."""
+        if grad_params is not None:
+            raise NotImplementedError('total_loss with traced grad_params is jax.grad plumbing; use update()')
+        B, args = self._batch_args(batch)
+        self._ensure_batch(B)
+        nz, nargs = self._noise_args(noise, B)
+        loss = C.c_float()
+        info = (C.c_float * 10)()
+        stream = self._stream(args + nargs)
+        self._check(self._lib.fql_total_loss(self._h, *[a.ptr for a in args], B, C.byref(nz) if nz else None,
+                                             C.byref(loss), info, stream))
+        return float(loss.value), {k: float(info[i]) for i, k in enumerate(INFO_KEYS[:10])}
+
+    def sample_actions(self, observations, seed=None, temperature=1.0, noises=None):
+        """agents/fql.py:135-153: clip(onestep(obs, N(0, I))).  `temperature` is accepted and ignored,
+        as in the reference.  Leading dims of `observations` are preserved ([od] -> [ad])."""
+        return self._eval(observations, noises, seed, flow=False)
+
+    def compute_flow_actions(self, observations, noises):
+        """agents/fql.py:155-171."""
+        return self._eval(observations, noises, None, flow=True)
+
+    def _eval(self, observations, noises, seed, flow):
+        od, ad = self.config['ob_dims'][0], self.config['action_dim']
+        is_torch = hasattr(observations, 'data_ptr')
+        lead = tuple(observations.shape[:-1])
+        if int(observations.shape[-1]) != od:
+            raise ValueError(f'observations last dim must be {od}, got {tuple(observations.shape)}')
+        n = int(np.prod(lead)) if lead else 1
+        o = _Arg(observations, (n, od))
+        z = _Arg(noises, (n, ad))
+        if is_torch and observations.is_cuda:
+            torch = _torch()
+            out = torch.empty(lead + (ad,), dtype=torch.float32, device=observations.device)
+            optr = out.data_ptr()
+        else:
+            out = np.empty(lead + (ad,), dtype=np.float32)
+            optr = out.ctypes.data
+        stream = self._stream([o, z])
+        if flow:
+            self._check(self._lib.fql_flow_actions(self._h, o.ptr, z.ptr, n, optr, stream))
+        else:
+            if seed is None and noises is None:
+                self._sample_calls += 1
+                sd = (self._seed << 20) ^ self._sample_calls
+            else:
+                sd = _seed_to_u64(seed)
+            self._check(self._lib.fql_sample_actions(self._h, o.ptr, n, z.ptr, sd & 0xFFFFFFFFFFFFFFFF, optr, stream))
+        return out
+
+    # -- device-resident dataset (utils/datasets.py Dataset/ReplayBuffer on the GPU) -------------
+    def upload_dataset(self, dataset, capacity: Optional[int] = None):
+        n = int(len(dataset['observations']))
+        cap = int(capacity) if capacity is not None else max(n, 1)
+        args = [_Arg(dataset[k]) for k in BATCH_KEYS]
+        self._check(self._lib.fql_dataset_upload(self._h, n, cap, *[a.ptr for a in args]))
+
+    def add_transition(self, transition):
+        o = _Arg(transition['observations']); a = _Arg(transition['actions']); no = _Arg(transition['next_observations'])
+        self._check(self._lib.fql_dataset_add(self._h, o.ptr, a.ptr, float(transition['rewards']),
+                                              float(transition['masks']), no.ptr))
+
+    def dataset_size(self):
+        s, p = C.c_int64(), C.c_int64()
+        self._check(self._lib.fql_dataset_size(self._h, C.byref(s), C.byref(p)))
+        return int(s.value), int(p.value)
+
+    def update_from_dataset(self, batch_size=None, idxs=None, noise=None, shard=(0, 0), want_info=False, stream=None):
+        """train_dataset.sample(B) + agent.update(batch) (main.py:201,216) without leaving the device."""
+        B = int(batch_size or self.config['batch_size'])
+        self._ensure_batch(B)
+        nz, nargs = self._noise_args(noise, B)
+        ip, keep = None, None
+        if idxs is not None:
+            if hasattr(idxs, 'data_ptr'):
+                keep = idxs.long().contiguous(); ip = keep.data_ptr()
+            else:
+                keep = np.ascontiguousarray(idxs, dtype=np.int64); ip = keep.ctypes.data
+            if (keep.numel() if hasattr(keep, 'numel') else keep.size) != B:
+                raise ValueError('idxs must have batch_size entries')
+        self._check(self._lib.fql_update_from_dataset(self._h, ip, B, int(shard[0]), int(shard[1]),
+                                                      C.byref(nz) if nz else None, None, stream))
+        self._keep = (keep, nargs)
+        return self, (self.read_info() if want_info else None)
+
+    # -- data-parallel halves (fql_amd/parallel.py drives these) ---------------------------------
+    def update_begin(self, batch=None, noise=None, idxs=None, shard=(0, 0), batch_size=None, stream=None):
+        if batch is not None:
+            B, args = self._batch_args(batch)
+            self._ensure_batch(B)
+            nz, nargs = self._noise_args(noise, B)
+            st = stream if stream is not None else self._stream(args + nargs)
+            self._check(self._lib.fql_update_begin(self._h, *[a.ptr for a in args], B, C.byref(nz) if nz else None, st))
+            self._keep = (args, nargs)
+        else:
+            B = int(batch_size or self.config['batch_size'])
+            self._ensure_batch(B)
+            nz, nargs = self._noise_args(noise, B)
+            ip, keep = None, None
+            if idxs is not None:
+                keep = np.ascontiguousarray(idxs, dtype=np.int64); ip = keep.ctypes.data
+            self._check(self._lib.fql_update_from_dataset_begin(self._h, ip, B, int(shard[0]), int(shard[1]),
+                                                                C.byref(nz) if nz else None, stream))
+            self._keep = (keep, nargs)
+
+    def update_end(self, stream=None):
+        self._check(self._lib.fql_update_end(self._h, None, stream))
+
+    def grad_buffer(self):
+        """(device pointer, number of floats) of the flat trainable-gradient buffer."""
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._lib.fql_grad_buffer(self._h, C.byref(p), C.byref(n)))
+        return int(p.value), int(n.value)
+
+    def set_grad_scale(self, scale: float):
+        self._check(self._lib.fql_set_grad_scale(self._h, float(scale)))
+
+    # -- parameters / optimizer state (reference tree layout, utils/flax_utils.py:16-50) ---------
+    def leaves(self):
+        out = []
+        name = C.create_string_buffer(256)
+        nd = C.c_int()
+        shp = (C.c_int64 * 4)()
+        for i in range(self._lib.fql_num_leaves(self._h)):
+            self._check(self._lib.fql_leaf_info(self._h, i, name, 256, C.byref(nd), shp))
+            out.append((name.value.decode(), tuple(int(shp[k]) for k in range(nd.value))))
+        return out
+
+    def _get_tree(self, getter):
+        tree: Dict[str, Any] = {}
+        for path, shape in self.leaves():
+            a = np.empty(shape, dtype=np.float32)
+            self._check(getter(path.encode(), a.ctypes.data, a.size))
+            node = tree
+            keys = path.split('/')
+            for k in keys[:-1]:
+                node = node.setdefault(k, {})
+            node[keys[-1]] = a
+        return tree
+
+    def _set_tree(self, tree, setter, prefix=''):
+        for k, v in tree.items():
+            p = f'{prefix}/{k}' if prefix else k
+            if isinstance(v, dict):
+                self._set_tree(v, setter, p)
+            else:
+                a = np.ascontiguousarray(np.asarray(v), dtype=np.float32)
+                self._check(setter(p.encode(), a.ctypes.data, a.size))
+
+    def get_params(self):
+        """agent.network.params as a nested dict of numpy arrays (reference leaf names and shapes)."""
+        return self._get_tree(lambda p, d, n: self._lib.fql_get_param(self._h, p, d, n))
+
+    def set_params(self, params):
+        self._set_tree(params, lambda p, d, n: self._lib.fql_set_param(self._h, p, d, n))
+
+    def get_opt_state(self):
+        """optax.adam state: {'count', 'mu', 'nu'}."""
+        c, s = C.c_int64(), C.c_int64()
+        self._check(self._lib.fql_get_step(self._h, C.byref(c), C.byref(s)))
+        return {'count': int(c.value), 'step': int(s.value),
+                'mu': self._get_tree(lambda p, d, n: self._lib.fql_get_opt_state(self._h, 0, p, d, n)),
+                'nu': self._get_tree(lambda p, d, n: self._lib.fql_get_opt_state(self._h, 1, p, d, n))}
+
+    def set_opt_state(self, state):
+        self._set_tree(state['mu'], lambda p, d, n: self._lib.fql_set_opt_state(self._h, 0, p, d, n))
+        self._set_tree(state['nu'], lambda p, d, n: self._lib.fql_set_opt_state(self._h, 1, p, d, n))
+        self._check(self._lib.fql_set_step(self._h, int(state['count']), int(state.get('step', state['count'] + 1))))
+
+    def stats(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self._lib.fql_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {'launches_per_update': int(a.value), 'macs_per_update': int(b.value), 'param_count': int(c.value)}

@@ -1,0 +1,1324 @@
+// FQL step engine for MI355X (gfx950): host side + C ABI (include/fql_amd.h).
+//
+// One stateful engine owns every device buffer of the step (params, Adam state, target network,
+// activations, dataset).  A training step is written ONCE as a straight-line program of tile tasks
+// with explicit read/write sets; a list scheduler levels the program (RAW/WAR/WAW on buffers), all
+// tasks of one kernel type in one level become ONE launch driven by a task table in HBM, and the
+// level sequence is captured into a hipGraph.  The kernel boundary is the only grid-wide barrier used
+// (cheapest on gfx950: ~1.3 us vs >4 us for an in-kernel grid barrier).
+//
+// Reference behaviour being replaced: agents/fql.py:22-171, utils/networks.py:34-61,153-235,
+// utils/flax_utils.py:90-159, utils/datasets.py:64-100,435-495 (zhouzypaul/fql).
+#include "../../include/fql_amd.h"
+#include "fql_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <random>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct HipError {
+    std::string msg;
+};
+#define HIP_CHECK(expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            char buf_[512];                                                                          \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            throw HipError{buf_};                                                                    \
+        }                                                                                            \
+    } while (0)
+
+struct Invalid {
+    std::string msg;
+};
+[[noreturn]] void invalid(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    throw Invalid{buf};
+}
+
+inline int pad16(int x) { return (x + 15) & ~15; }
+
+// ------------------------------------------------------------------------------------------------
+// networks in the parameter arena
+// ------------------------------------------------------------------------------------------------
+struct Layer {
+    int in, out, in_p, out_p;
+    size_t w, b;      // arena offsets (floats)
+    bool ln;          // LayerNorm after this layer's GELU
+    size_t g, be;     // LN scale / bias offsets
+};
+struct Net {
+    std::vector<Layer> layers;
+    size_t off = 0, size = 0;
+    int in() const { return layers.front().in; }
+    int in_p() const { return layers.front().in_p; }
+    int nl() const { return (int)layers.size(); }
+};
+enum { NET_C0 = 0, NET_C1, NET_BC, NET_OS, NET_T0, NET_T1, NUM_NETS };
+
+struct Segment {  // one contiguous padded block of a leaf
+    size_t off;
+    int rows, cols, rows_p, cols_p;  // logical and padded 2-D shape (vectors: rows = 1)
+};
+struct Leaf {
+    std::string name;
+    int ndim;
+    int64_t shape[4];
+    std::vector<Segment> segs;  // 1 (actors) or 2 (ensemble members)
+    bool trainable;
+    int train_id;  // index among trainable leaves or -1
+};
+
+// ------------------------------------------------------------------------------------------------
+// program = ordered ops with read/write sets -> levels -> launches
+// ------------------------------------------------------------------------------------------------
+enum OpType { OP_GEMM, OP_WGRAD, OP_LNBWD, OP_PREP, OP_POSTOS, OP_LOSS_CRITIC, OP_LOSS_Q, OP_LOSS_BC,
+              OP_LOSS_ACTOR, OP_BEGIN, OP_ADAM, OP_FINALIZE };
+
+struct Op {
+    OpType type;
+    std::vector<const void*> reads, writes;
+    GemmTask gemm;
+    WgradTask wgrad;
+    LnBwdTask ln;
+    PrepArgs prep;
+    PostOsArgs postos;
+    LossCriticArgs lc;
+    LossQArgs lq;
+    LossBcArgs lb;
+    LossActorArgs la;
+    int fin_mode = 0;
+    int level = 0;
+};
+
+struct Launch {
+    OpType type;
+    int grid = 0, ntasks = 0;
+    size_t lds = 0;
+    void* table = nullptr;  // device task table (GEMM/WGRAD/LNBWD)
+    Op op;                  // arg-struct kernels
+};
+
+struct Program {
+    std::vector<Op> ops;
+    std::vector<Launch> launches;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int64_t macs = 0;
+};
+
+struct PassBuf {
+    int net = 0, M = 0;
+    const void* id = nullptr;          // dependency id base
+    float* x0 = nullptr;               // [M, in_p]
+    std::vector<float*> g, xn, z, stats;  // per hidden layer
+    float* out = nullptr;              // [M, out_p]
+    std::vector<float*> dz;            // per layer gradient wrt pre-activation / output
+    std::vector<float*> dy;            // LN nets: gradient wrt LN output
+    float* dx0 = nullptr;
+};
+
+}  // namespace
+
+struct fql_engine {
+    fql_config cfg{};
+    uint64_t seed = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    Net nets[NUM_NETS];
+    size_t n_train = 0, n_total = 0, critic_size = 0;
+    float *P = nullptr, *G = nullptr, *Mu = nullptr, *Nu = nullptr;
+    std::vector<Leaf> leaves;
+    int n_train_leaves = 0;
+    AdamChunk* d_chunks = nullptr;
+    int n_chunks = 0;
+
+    DevState* d_state = nullptr;
+    SrcDesc* d_src = nullptr;
+    SrcDesc h_src_shadow{};
+    bool src_valid = false;
+    SrcDesc* h_src_ring = nullptr;
+    int src_ring_pos = 0;
+
+    // workspace (per batch size)
+    int B = 0;
+    std::vector<void*> ws_allocs;
+    float *in_obs = nullptr, *in_act = nullptr, *in_rew = nullptr, *in_mask = nullptr, *in_nobs = nullptr;
+    float* in_noise[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int64_t* in_idx = nullptr;
+    float *X_os = nullptr, *X_bc = nullptr, *X_eu = nullptr, *X_c1 = nullptr, *X_c2 = nullptr, *X_ct = nullptr;
+    float *vel = nullptr, *w_rew = nullptr, *w_mask = nullptr, *w_act = nullptr, *tgt = nullptr;
+    PassBuf p_os, p_os_bwd, p_bc, p_eu, p_c1[2], p_c2[2], p_ct[2];
+    Program prog_fwdbwd, prog_opt, prog_loss;
+    bool began = false;
+
+    // dataset
+    float *ds_obs = nullptr, *ds_act = nullptr, *ds_rew = nullptr, *ds_mask = nullptr, *ds_nobs = nullptr;
+    float* ds_row = nullptr;
+    int64_t ds_size = 0, ds_cap = 0, ds_ptr = 0;
+
+    // eval (sample_actions / flow_actions) workspaces keyed by padded row count
+    struct Eval {
+        int n_pad = 0;
+        std::vector<void*> allocs;
+        float *X = nullptr, *Xf = nullptr, *tgt = nullptr;
+        PassBuf p_os, p_eu;
+        Program prog_os, prog_flow;
+        float *st_obs = nullptr, *st_noise = nullptr, *st_out = nullptr;
+    };
+    std::map<int, std::unique_ptr<Eval>> evals;
+
+    int64_t launches_per_update = 0;
+
+    // ---------------------------------------------------------------------------------------
+    float* dalloc(std::vector<void*>& owner, size_t nfloats) {
+        void* p = nullptr;
+        const size_t bytes = std::max<size_t>(nfloats, 4) * sizeof(float);
+        HIP_CHECK(hipMalloc(&p, bytes));
+        HIP_CHECK(hipMemset(p, 0, bytes));
+        owner.push_back(p);
+        return (float*)p;
+    }
+
+    void build_nets() {
+        const int od = cfg.obs_dim, ad = cfg.act_dim;
+        auto make = [&](int in, const int32_t* hid, int nh, int out, bool ln) {
+            Net n;
+            int prev = in;
+            for (int i = 0; i <= nh; ++i) {
+                Layer L{};
+                L.in = prev;
+                L.out = (i < nh) ? hid[i] : out;
+                L.in_p = pad16(L.in);
+                L.out_p = pad16(L.out);
+                L.ln = ln && i < nh;
+                n.layers.push_back(L);
+                prev = L.out;
+            }
+            return n;
+        };
+        nets[NET_C0] = make(od + ad, cfg.value_hidden, cfg.num_value_hidden, 1, cfg.layer_norm != 0);
+        nets[NET_C1] = nets[NET_C0];
+        nets[NET_BC] = make(od + ad + 1, cfg.actor_hidden, cfg.num_actor_hidden, ad, cfg.actor_layer_norm != 0);
+        nets[NET_OS] = make(od + ad, cfg.actor_hidden, cfg.num_actor_hidden, ad, cfg.actor_layer_norm != 0);
+        nets[NET_T0] = nets[NET_C0];
+        nets[NET_T1] = nets[NET_C0];
+        size_t off = 0;
+        for (int ni = 0; ni < NUM_NETS; ++ni) {
+            Net& n = nets[ni];
+            n.off = off;
+            for (Layer& L : n.layers) {
+                L.w = off; off += (size_t)L.in_p * L.out_p;
+                L.b = off; off += L.out_p;
+                if (L.ln) {
+                    L.g = off; off += L.out_p;
+                    L.be = off; off += L.out_p;
+                }
+            }
+            n.size = off - n.off;
+            if (ni == NET_C1) critic_size = off;
+            if (ni == NET_OS) n_train = off;
+        }
+        n_total = off;
+        for (int ni = 0; ni < NUM_NETS; ++ni)
+            for (const Layer& L : nets[ni].layers)
+                if (L.in_p > 1024 || L.out_p > 1024) invalid("layer widths above 1024 are not supported (got %d -> %d)", L.in, L.out);
+        if (nets[NET_T0].off - n_train != 0 || nets[NET_T0].size + nets[NET_T1].size != critic_size)
+            invalid("internal: target arena layout mismatch");
+    }
+
+    void build_leaves() {
+        leaves.clear();
+        struct Mod { const char* name; const char* sub; int n0, n1; bool train; };
+        const Mod mods[4] = {{"modules_actor_bc_flow", "mlp", NET_BC, -1, true},
+                             {"modules_actor_onestep_flow", "mlp", NET_OS, -1, true},
+                             {"modules_critic", "value_net", NET_C0, NET_C1, true},
+                             {"modules_target_critic", "value_net", NET_T0, NET_T1, false}};
+        int tid = 0;
+        for (const Mod& m : mods) {
+            const Net& n0 = nets[m.n0];
+            const bool ens = m.n1 >= 0;
+            auto add = [&](const std::string& name, bool matrix, int rows, int cols, size_t o0, size_t o1, int rp, int cp) {
+                Leaf lf;
+                lf.name = name;
+                int d = 0;
+                if (ens) lf.shape[d++] = 2;
+                if (matrix) lf.shape[d++] = rows;
+                lf.shape[d++] = cols;
+                lf.ndim = d;
+                for (int k = d; k < 4; ++k) lf.shape[k] = 1;
+                lf.segs.push_back(Segment{o0, matrix ? rows : 1, cols, matrix ? rp : 1, cp});
+                if (ens) lf.segs.push_back(Segment{o1, matrix ? rows : 1, cols, matrix ? rp : 1, cp});
+                lf.trainable = m.train;
+                lf.train_id = m.train ? tid++ : -1;
+                leaves.push_back(lf);
+            };
+            const std::string base = std::string(m.name) + "/" + m.sub + "/";
+            // jax dict order: Dense_0..Dense_L (bias, kernel), then LayerNorm_0.. (bias, scale)
+            for (int i = 0; i < n0.nl(); ++i) {
+                const Layer& a = n0.layers[i];
+                const Layer* b = ens ? &nets[m.n1].layers[i] : nullptr;
+                add(base + "Dense_" + std::to_string(i) + "/bias", false, 1, a.out, a.b, b ? b->b : 0, 1, a.out_p);
+                add(base + "Dense_" + std::to_string(i) + "/kernel", true, a.in, a.out, a.w, b ? b->w : 0, a.in_p, a.out_p);
+            }
+            for (int i = 0; i < n0.nl(); ++i) {
+                const Layer& a = n0.layers[i];
+                if (!a.ln) continue;
+                const Layer* b = ens ? &nets[m.n1].layers[i] : nullptr;
+                add(base + "LayerNorm_" + std::to_string(i) + "/bias", false, 1, a.out, a.be, b ? b->be : 0, 1, a.out_p);
+                add(base + "LayerNorm_" + std::to_string(i) + "/scale", false, 1, a.out, a.g, b ? b->g : 0, 1, a.out_p);
+            }
+        }
+        n_train_leaves = tid;
+        if (n_train_leaves > 128) invalid("too many trainable leaves (%d)", n_train_leaves);
+        // Adam chunks: contiguous pieces of one leaf, <= 4096 elements
+        std::vector<AdamChunk> ch;
+        for (const Leaf& lf : leaves) {
+            if (!lf.trainable) continue;
+            for (const Segment& s : lf.segs) {
+                const size_t len = (size_t)s.rows_p * s.cols_p;
+                for (size_t o = 0; o < len; o += 4096)
+                    ch.push_back(AdamChunk{(int)(s.off + o), (int)std::min<size_t>(4096, len - o), lf.train_id});
+            }
+        }
+        n_chunks = (int)ch.size();
+        HIP_CHECK(hipMalloc((void**)&d_chunks, ch.size() * sizeof(AdamChunk)));
+        HIP_CHECK(hipMemcpy(d_chunks, ch.data(), ch.size() * sizeof(AdamChunk), hipMemcpyHostToDevice));
+    }
+
+    const Leaf* find_leaf(const char* name) const {
+        for (const Leaf& l : leaves)
+            if (l.name == name) return &l;
+        return nullptr;
+    }
+    static size_t leaf_count(const Leaf& l) {
+        size_t n = 1;
+        for (int i = 0; i < l.ndim; ++i) n *= (size_t)l.shape[i];
+        return n;
+    }
+    void leaf_io(const Leaf& lf, float* arena, float* host, bool to_device) {
+        HIP_CHECK(hipStreamSynchronize(stream));
+        size_t ho = 0;
+        for (const Segment& s : lf.segs) {
+            HIP_CHECK(hipMemcpy2D(to_device ? (void*)(arena + s.off) : (void*)(host + ho), (to_device ? s.cols_p : s.cols) * sizeof(float),
+                                  to_device ? (const void*)(host + ho) : (const void*)(arena + s.off),
+                                  (to_device ? s.cols : s.cols_p) * sizeof(float), s.cols * sizeof(float), s.rows,
+                                  to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
+            ho += (size_t)s.rows * s.cols;
+        }
+    }
+
+    void init_params() {
+        // utils/networks.py:9-11 Glorot-uniform kernels; flax Dense bias 0; LayerNorm scale 1 / bias 0;
+        // agents/fql.py:241-242 target := critic.  (Host RNG: JAX's threefry init is not reproducible.)
+        std::vector<float> h(n_total, 0.f);
+        std::mt19937_64 gen(seed * 0x9E3779B97F4A7C15ull + 0x1234567ull);
+        for (int ni = 0; ni <= NET_OS; ++ni)
+            for (const Layer& L : nets[ni].layers) {
+                const double lim = std::sqrt(6.0 / (double)(L.in + L.out));
+                std::uniform_real_distribution<double> U(-lim, lim);
+                for (int r = 0; r < L.in; ++r)
+                    for (int c = 0; c < L.out; ++c) h[L.w + (size_t)r * L.out_p + c] = (float)U(gen);
+                if (L.ln)
+                    for (int c = 0; c < L.out; ++c) h[L.g + c] = 1.0f;
+            }
+        std::memcpy(h.data() + n_train, h.data(), critic_size * sizeof(float));
+        HIP_CHECK(hipMemcpy(P, h.data(), n_total * sizeof(float), hipMemcpyHostToDevice));
+    }
+
+    // ---------------------------------------------------------------------------------------
+    // pass buffers
+    // ---------------------------------------------------------------------------------------
+    PassBuf make_pass(std::vector<void*>& owner, int net, int M, float* x0, bool bwd, bool input_grad) {
+        const Net& n = nets[net];
+        PassBuf p;
+        p.net = net; p.M = M; p.x0 = x0;
+        const int L = n.nl() - 1;
+        for (int l = 0; l < L; ++l) {
+            const int H = n.layers[l].out_p;
+            p.g.push_back(dalloc(owner, (size_t)M * H));
+            p.z.push_back(dalloc(owner, (size_t)M * H));
+            if (n.layers[l].ln) {
+                p.xn.push_back(dalloc(owner, (size_t)M * H));
+                p.stats.push_back(dalloc(owner, (size_t)M * 2));
+            } else {
+                p.xn.push_back(p.g.back());
+                p.stats.push_back(nullptr);
+            }
+        }
+        p.out = dalloc(owner, (size_t)M * n.layers[L].out_p);
+        if (bwd) {
+            for (int l = 0; l <= L; ++l) p.dz.push_back(dalloc(owner, (size_t)M * n.layers[l].out_p));
+            for (int l = 0; l < L; ++l) p.dy.push_back(n.layers[l].ln ? dalloc(owner, (size_t)M * n.layers[l].out_p) : nullptr);
+            if (input_grad) p.dx0 = dalloc(owner, (size_t)M * n.in_p());
+        }
+        return p;
+    }
+
+    // forward of one pass appended to a program.  final_flags: epilogue of the last layer.
+    void emit_forward(Program& pr, const PassBuf& p, bool save, int final_flags = 0, float* aux = nullptr,
+                      float* aux2 = nullptr, float f0 = 0.f, float f1 = 0.f) {
+        const Net& n = nets[p.net];
+        const int L = n.nl() - 1;
+        for (int l = 0; l <= L; ++l) {
+            const Layer& ly = n.layers[l];
+            Op op{};
+            op.type = OP_GEMM;
+            GemmTask& t = op.gemm;
+            const bool a_ln = l > 0 && n.layers[l - 1].ln;
+            t.A = (l == 0) ? p.x0 : p.g[l - 1];
+            t.lda = ly.in_p;
+            t.B = P + ly.w; t.ldb = ly.out_p;
+            t.bias = P + ly.b;
+            t.M = p.M; t.N = ly.out_p; t.K = ly.in_p;
+            t.ldc = ly.out_p;
+            t.flags = GF_BIAS;
+            op.reads = {t.A, t.B};
+            if (a_ln) {
+                t.flags |= GF_A_LN;
+                t.ln_g = P + n.layers[l - 1].g; t.ln_b = P + n.layers[l - 1].be;
+                t.ln_width = n.layers[l - 1].out;
+                if (save) {
+                    t.flags |= GF_LN_WRITE;
+                    t.ln_xout = p.xn[l - 1]; t.ln_stats = p.stats[l - 1];
+                    op.writes.push_back(t.ln_xout);
+                    op.writes.push_back(t.ln_stats);
+                }
+            }
+            if (l < L) {
+                t.C = p.g[l];
+                t.flags |= GF_GELU;
+                if (save) { t.flags |= GF_SAVE_Z; t.Zout = p.z[l]; op.writes.push_back(t.Zout); }
+                op.writes.push_back(t.C);
+            } else {
+                t.C = p.out;
+                t.flags |= final_flags;
+                if (final_flags & GF_EULER) {
+                    t.aux = aux; t.aux2 = aux2;
+                    t.i0 = n.in_p(); t.i1 = cfg.obs_dim; t.i2 = cfg.act_dim;
+                    t.f0 = f0; t.f1 = f1;
+                    op.reads.push_back(aux);
+                    op.writes.push_back(aux);
+                    if (aux2) op.writes.push_back(aux2);
+                } else {
+                    op.writes.push_back(t.C);
+                }
+            }
+            pr.ops.push_back(op);
+        }
+    }
+
+    // backward of one pass: dz[L] must already hold dLoss/dOut.  rows: view [row_off, row_off+M) of a
+    // taller forward pass (one-step actor: only the (obs, z) block is differentiated).
+    void emit_backward(Program& pr, const PassBuf& p, int row_off, int M, bool param_grads, bool input_grad) {
+        const Net& n = nets[p.net];
+        const int L = n.nl() - 1;
+        auto rows = [&](float* base, int ld) { return base + (size_t)row_off * ld; };
+        for (int l = L; l >= 0; --l) {
+            const Layer& ly = n.layers[l];
+            float* dz = p.dz[l];
+            const float* xin = (l == 0) ? rows(p.x0, ly.in_p) : rows(p.xn[l - 1], ly.in_p);
+            const void* xin_id = (l == 0) ? (const void*)p.x0 : (const void*)p.xn[l - 1];
+            if (param_grads) {
+                Op op{};
+                op.type = OP_WGRAD;
+                WgradTask& w = op.wgrad;
+                w.X = xin; w.ldx = ly.in_p;
+                w.dZ = dz; w.ldz = ly.out_p;
+                w.dW = G + ly.w; w.ldw = ly.out_p;
+                w.db = G + ly.b;
+                w.M = M; w.Kin = ly.in_p; w.N = ly.out_p;
+                op.reads = {xin_id, dz};
+                op.writes = {w.dW, w.db};
+                pr.ops.push_back(op);
+            }
+            if (l == 0 && !input_grad) break;
+            // dgrad: dX = dZ W^T
+            Op op{};
+            op.type = OP_GEMM;
+            GemmTask& t = op.gemm;
+            t.A = dz; t.lda = ly.out_p;
+            t.B = P + ly.w; t.ldb = ly.out_p;
+            t.M = M; t.N = ly.in_p; t.K = ly.out_p;
+            t.ldc = ly.in_p;
+            t.flags = GF_TRANS_B;
+            op.reads = {dz, t.B};
+            if (l == 0) {
+                t.C = p.dx0;
+                op.writes = {t.C};
+                pr.ops.push_back(op);
+                break;
+            }
+            const Layer& prev = n.layers[l - 1];
+            if (prev.ln) {
+                t.C = p.dy[l - 1];
+                op.writes = {t.C};
+                pr.ops.push_back(op);
+                Op lo{};
+                lo.type = OP_LNBWD;
+                LnBwdTask& q = lo.ln;
+                q.dY = p.dy[l - 1];
+                q.Z = rows(p.z[l - 1], prev.out_p);
+                q.stats = p.stats[l - 1] + (size_t)row_off * 2;
+                q.gamma = P + prev.g;
+                q.dZ = p.dz[l - 1];
+                q.dgamma = param_grads ? G + prev.g : nullptr;
+                q.dbeta = param_grads ? G + prev.be : nullptr;
+                q.M = M; q.H = prev.out_p; q.ld = prev.out_p; q.width = prev.out;
+                lo.reads = {q.dY, p.z[l - 1], p.stats[l - 1], q.gamma};
+                lo.writes = {q.dZ};
+                if (param_grads) { lo.writes.push_back(q.dgamma); lo.writes.push_back(q.dbeta); }
+                pr.ops.push_back(lo);
+            } else {
+                t.C = p.dz[l - 1];
+                t.flags |= GF_GELUGRAD;
+                t.Zprev = rows(p.z[l - 1], prev.out_p);
+                op.reads.push_back(p.z[l - 1]);
+                op.writes = {t.C};
+                pr.ops.push_back(op);
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------------------------------
+    // scheduling + launch tables + graph capture
+    // ---------------------------------------------------------------------------------------
+    static bool is_table(OpType t) { return t == OP_GEMM || t == OP_WGRAD || t == OP_LNBWD; }
+
+    void schedule(Program& pr, std::vector<void*>& owner) {
+        std::map<const void*, int> last_write;               // buffer -> level of last writer
+        std::map<const void*, int> last_read;                // buffer -> max level of readers since last write
+        for (Op& op : pr.ops) {
+            int lv = 0;
+            for (const void* r : op.reads) {
+                auto it = last_write.find(r);
+                if (it != last_write.end()) lv = std::max(lv, it->second + 1);
+            }
+            for (const void* w : op.writes) {
+                auto it = last_write.find(w);
+                if (it != last_write.end()) lv = std::max(lv, it->second + 1);
+                auto ir = last_read.find(w);
+                if (ir != last_read.end()) lv = std::max(lv, ir->second + 1);
+            }
+            op.level = lv;
+            for (const void* r : op.reads) {
+                auto& x = last_read[r];
+                x = std::max(x, lv);
+            }
+            for (const void* w : op.writes) {
+                last_write[w] = lv;
+                last_read.erase(w);
+            }
+        }
+        int maxlv = 0;
+        for (const Op& op : pr.ops) maxlv = std::max(maxlv, op.level);
+        pr.launches.clear();
+        for (int lv = 0; lv <= maxlv; ++lv) {
+            for (int ty = 0; ty <= OP_FINALIZE; ++ty) {
+                std::vector<const Op*> sel;
+                for (const Op& op : pr.ops)
+                    if (op.level == lv && op.type == ty) sel.push_back(&op);
+                if (sel.empty()) continue;
+                if (!is_table((OpType)ty)) {
+                    for (const Op* o : sel) {
+                        Launch L;
+                        L.type = (OpType)ty;
+                        L.op = *o;
+                        pr.launches.push_back(L);
+                    }
+                    continue;
+                }
+                Launch L;
+                L.type = (OpType)ty;
+                L.ntasks = (int)sel.size();
+                int tile = 0;
+                if (ty == OP_GEMM) {
+                    std::vector<GemmTask> tb;
+                    for (const Op* o : sel) {
+                        GemmTask t = o->gemm;
+                        t.ntn = (t.N + 63) / 64;
+                        t.tile0 = tile;
+                        tile += (t.M / 16) * t.ntn;
+                        L.lds = std::max(L.lds, (size_t)16 * (t.K + 4) * sizeof(float));
+                        tb.push_back(t);
+                    }
+                    L.table = dalloc(owner, tb.size() * sizeof(GemmTask) / sizeof(float) + 4);
+                    HIP_CHECK(hipMemcpy(L.table, tb.data(), tb.size() * sizeof(GemmTask), hipMemcpyHostToDevice));
+                } else if (ty == OP_WGRAD) {
+                    std::vector<WgradTask> tb;
+                    for (const Op* o : sel) {
+                        WgradTask t = o->wgrad;
+                        t.ntn = (t.N + 63) / 64;
+                        t.tile0 = tile;
+                        tile += (t.Kin / 16) * t.ntn;
+                        tb.push_back(t);
+                    }
+                    L.table = dalloc(owner, tb.size() * sizeof(WgradTask) / sizeof(float) + 4);
+                    HIP_CHECK(hipMemcpy(L.table, tb.data(), tb.size() * sizeof(WgradTask), hipMemcpyHostToDevice));
+                } else {
+                    std::vector<LnBwdTask> tb;
+                    for (const Op* o : sel) {
+                        LnBwdTask t = o->ln;
+                        t.ntiles_rows = (t.M + 3) / 4;
+                        t.tile0 = tile;
+                        tile += t.ntiles_rows + (t.dgamma ? (t.H + 63) / 64 : 0);
+                        tb.push_back(t);
+                    }
+                    L.table = dalloc(owner, tb.size() * sizeof(LnBwdTask) / sizeof(float) + 4);
+                    HIP_CHECK(hipMemcpy(L.table, tb.data(), tb.size() * sizeof(LnBwdTask), hipMemcpyHostToDevice));
+                }
+                L.grid = tile;
+                pr.launches.push_back(L);
+            }
+        }
+    }
+
+    void run_launches(const Program& pr, hipStream_t s) {
+        for (const Launch& L : pr.launches) {
+            switch (L.type) {
+                case OP_GEMM:
+                    hipLaunchKernelGGL(fql_gemm16_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
+                    break;
+                case OP_WGRAD:
+                    hipLaunchKernelGGL(fql_wgrad_kernel, dim3(L.grid), dim3(FQL_THREADS), 0, s, (const WgradTask*)L.table, L.ntasks);
+                    break;
+                case OP_LNBWD:
+                    hipLaunchKernelGGL(fql_lnbwd_kernel, dim3(L.grid), dim3(FQL_THREADS), 0, s, (const LnBwdTask*)L.table, L.ntasks);
+                    break;
+                case OP_PREP:
+                    hipLaunchKernelGGL(fql_prep_kernel, dim3((L.op.prep.B + 3) / 4), dim3(FQL_THREADS), 0, s, L.op.prep);
+                    break;
+                case OP_POSTOS:
+                    hipLaunchKernelGGL(fql_post_onestep_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.postos);
+                    break;
+                case OP_LOSS_CRITIC:
+                    hipLaunchKernelGGL(fql_loss_critic_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.lc);
+                    break;
+                case OP_LOSS_Q:
+                    hipLaunchKernelGGL(fql_loss_q_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.lq);
+                    break;
+                case OP_LOSS_BC:
+                    hipLaunchKernelGGL(fql_loss_bc_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.lb);
+                    break;
+                case OP_LOSS_ACTOR:
+                    hipLaunchKernelGGL(fql_loss_actor_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.la);
+                    break;
+                case OP_BEGIN:
+                    hipLaunchKernelGGL(fql_begin_step_kernel, dim3(1), dim3(64), 0, s, d_state, d_src);
+                    break;
+                case OP_ADAM: {
+                    AdamArgs a{P, G, Mu, Nu, P + n_train, d_chunks, d_state, (int)critic_size, cfg.lr, cfg.tau};
+                    hipLaunchKernelGGL(fql_adam_kernel, dim3(n_chunks), dim3(FQL_THREADS), 0, s, a);
+                    break;
+                }
+                case OP_FINALIZE:
+                    hipLaunchKernelGGL(fql_finalize_kernel, dim3(1), dim3(64), 0, s, d_state, n_train_leaves, L.op.fin_mode);
+                    break;
+            }
+        }
+        HIP_CHECK(hipGetLastError());
+    }
+
+    void capture(Program& pr) {
+        if (pr.exec) { hipGraphExecDestroy(pr.exec); pr.exec = nullptr; }
+        if (pr.graph) { hipGraphDestroy(pr.graph); pr.graph = nullptr; }
+        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        try {
+            run_launches(pr, stream);
+        } catch (...) {
+            hipGraph_t g = nullptr;
+            hipStreamEndCapture(stream, &g);
+            if (g) hipGraphDestroy(g);
+            throw;
+        }
+        HIP_CHECK(hipStreamEndCapture(stream, &pr.graph));
+        HIP_CHECK(hipGraphInstantiate(&pr.exec, pr.graph, nullptr, nullptr, 0));
+    }
+
+    void free_program(Program& pr) {
+        if (pr.exec) hipGraphExecDestroy(pr.exec);
+        if (pr.graph) hipGraphDestroy(pr.graph);
+        pr = Program{};
+    }
+
+    // ---------------------------------------------------------------------------------------
+    // the training step as a program (agents/fql.py:94-133)
+    // ---------------------------------------------------------------------------------------
+    void build_step_program(Program& pr, bool with_grads) {
+        const int od = cfg.obs_dim, ad = cfg.act_dim;
+        const int inp_c = nets[NET_OS].in_p(), inp_b = nets[NET_BC].in_p();
+        const int ap = pad16(ad);
+        DevState* st = d_state;
+        const void* INFO = &st->info[0];
+        {   // batch gather + noise + every network input
+            Op op{};
+            op.type = OP_PREP;
+            op.prep = PrepArgs{d_src, st, seed, B, od, ad, inp_c, inp_b, ap, X_os, X_bc, X_eu, X_c1, X_c2, X_ct, vel, w_rew, w_mask, w_act};
+            op.writes = {X_os, X_bc, X_eu, X_c1, X_c2, X_ct, vel, w_rew, w_mask, w_act};
+            pr.ops.push_back(op);
+        }
+        // one-step actor on [next_obs|eps1 ; obs|z ; obs|eps2]  (agents/fql.py:25,65,82)
+        emit_forward(pr, p_os, with_grads);
+        {
+            Op op{};
+            op.type = OP_POSTOS;
+            op.postos = PostOsArgs{p_os.out, w_act, X_ct, X_c2, st, B, od, ad, inp_c, ap};
+            op.reads = {p_os.out, w_act};
+            op.writes = {X_ct, X_c2, INFO};
+            pr.ops.push_back(op);
+        }
+        // critic(obs, actions) with grad params; target critic(next_obs, next_actions)  (fql.py:28,36)
+        for (int e = 0; e < 2; ++e) emit_forward(pr, p_c1[e], with_grads);
+        for (int e = 0; e < 2; ++e) emit_forward(pr, p_ct[e], false);
+        {
+            Op op{};
+            op.type = OP_LOSS_CRITIC;
+            op.lc = LossCriticArgs{p_c1[0].out, p_c1[1].out, p_ct[0].out, p_ct[1].out, w_rew, w_mask,
+                                   with_grads ? p_c1[0].dz.back() : nullptr, with_grads ? p_c1[1].dz.back() : nullptr,
+                                   st, B, cfg.q_agg, with_grads ? 1 : 0, cfg.discount};
+            op.reads = {p_c1[0].out, p_c1[1].out, p_ct[0].out, p_ct[1].out, w_rew, w_mask};
+            op.writes = {INFO};
+            if (with_grads) { op.writes.push_back(p_c1[0].dz.back()); op.writes.push_back(p_c1[1].dz.back()); }
+            pr.ops.push_back(op);
+        }
+        if (with_grads)
+            for (int e = 0; e < 2; ++e) emit_backward(pr, p_c1[e], 0, B, true, false);
+        // BC flow-matching pass (fql.py:52-59)
+        emit_forward(pr, p_bc, with_grads);
+        {
+            Op op{};
+            op.type = OP_LOSS_BC;
+            op.lb = LossBcArgs{p_bc.out, vel, with_grads ? p_bc.dz.back() : nullptr, st, B, ad, ap, with_grads ? 1 : 0};
+            op.reads = {p_bc.out, vel};
+            op.writes = {INFO};
+            if (with_grads) op.writes.push_back(p_bc.dz.back());
+            pr.ops.push_back(op);
+        }
+        if (with_grads) emit_backward(pr, p_bc, 0, B, true, false);
+        // Q term: critic(obs, clip(actor_actions)) with stored params, input-differentiable (fql.py:69-76)
+        for (int e = 0; e < 2; ++e) emit_forward(pr, p_c2[e], with_grads);
+        {
+            Op op{};
+            op.type = OP_LOSS_Q;
+            op.lq = LossQArgs{p_c2[0].out, p_c2[1].out, with_grads ? p_c2[0].dz.back() : nullptr,
+                              with_grads ? p_c2[1].dz.back() : nullptr, st, B, cfg.normalize_q_loss, with_grads ? 1 : 0};
+            op.reads = {p_c2[0].out, p_c2[1].out};
+            op.writes = {INFO};
+            if (with_grads) { op.writes.push_back(p_c2[0].dz.back()); op.writes.push_back(p_c2[1].dz.back()); }
+            pr.ops.push_back(op);
+        }
+        if (with_grads)
+            for (int e = 0; e < 2; ++e) emit_backward(pr, p_c2[e], 0, B, false, true);
+        // Euler chain through the BC flow (fql.py:155-171): flow_steps sequential forwards
+        const int fs = cfg.flow_steps;
+        for (int s = 0; s < fs; ++s)
+            emit_forward(pr, p_eu, false, GF_EULER | (s == fs - 1 ? GF_EULER_LAST : 0), X_eu, tgt, 1.0f / (float)fs,
+                         (float)(s + 1) / (float)fs);
+        {
+            Op op{};
+            op.type = OP_LOSS_ACTOR;
+            op.la = LossActorArgs{p_os.out + (size_t)B * ap, tgt, with_grads ? p_c2[0].dx0 : nullptr,
+                                  with_grads ? p_c2[1].dx0 : nullptr, with_grads ? p_os_bwd.dz.back() : nullptr, st, B, od, ad,
+                                  inp_c, ap, with_grads ? 1 : 0, cfg.alpha};
+            op.reads = {p_os.out, tgt, INFO};
+            op.writes = {INFO};
+            if (with_grads) {
+                op.reads.push_back(p_c2[0].dx0); op.reads.push_back(p_c2[1].dx0);
+                op.writes.push_back(p_os_bwd.dz.back());
+            }
+            pr.ops.push_back(op);
+        }
+        if (with_grads) emit_backward(pr, p_os_bwd, B, B, true, false);
+        if (!with_grads) {
+            Op op{};
+            op.type = OP_FINALIZE;
+            op.fin_mode = 0;
+            op.reads = {INFO};
+            op.writes = {INFO};
+            pr.ops.push_back(op);
+        }
+    }
+
+    void build_opt_program(Program& pr) {
+        DevState* st = d_state;
+        const void* INFO = &st->info[0];
+        Op b{};
+        b.type = OP_BEGIN;
+        b.writes = {st};
+        pr.ops.push_back(b);
+        Op a{};
+        a.type = OP_ADAM;
+        a.reads = {st, G};
+        a.writes = {P, Mu, Nu, INFO};
+        pr.ops.push_back(a);
+        Op f{};
+        f.type = OP_FINALIZE;
+        f.fin_mode = 1;
+        f.reads = {INFO};
+        f.writes = {INFO, st};
+        pr.ops.push_back(f);
+    }
+
+    int64_t macs_per_update() const {
+        auto macs = [&](const Net& n) { int64_t m = 0; for (const Layer& L : n.layers) m += (int64_t)L.in * L.out; return m; };
+        auto first = [&](const Net& n) { return (int64_t)n.layers[0].in * n.layers[0].out; };
+        const int64_t os = macs(nets[NET_OS]), bc = macs(nets[NET_BC]), cr = macs(nets[NET_C0]);
+        const int64_t fwd = 3 * os + (cfg.flow_steps + 1) * bc + 6 * cr;
+        const int64_t bwd = 2 * (2 * cr - first(nets[NET_C0])) + (2 * bc - first(nets[NET_BC])) + (2 * os - first(nets[NET_OS])) + 2 * cr;
+        return (fwd + bwd) * (int64_t)B;
+    }
+
+    void free_workspace() {
+        free_program(prog_fwdbwd);
+        free_program(prog_opt);
+        free_program(prog_loss);
+        for (void* p : ws_allocs) hipFree(p);
+        ws_allocs.clear();
+    }
+
+    void build_workspace(int batch) {
+        if (batch <= 0 || batch % 16 != 0) invalid("batch_size must be a positive multiple of 16 (got %d)", batch);
+        HIP_CHECK(hipStreamSynchronize(stream));
+        free_workspace();
+        B = batch;
+        const int od = cfg.obs_dim, ad = cfg.act_dim;
+        const int inp_c = nets[NET_OS].in_p(), inp_b = nets[NET_BC].in_p();
+        auto& W = ws_allocs;
+        in_obs = dalloc(W, (size_t)B * od); in_nobs = dalloc(W, (size_t)B * od);
+        in_act = dalloc(W, (size_t)B * ad); in_rew = dalloc(W, B); in_mask = dalloc(W, B);
+        for (int i = 0; i < 5; ++i) in_noise[i] = dalloc(W, (size_t)B * ad);
+        in_idx = (int64_t*)dalloc(W, (size_t)B * 2);
+        X_os = dalloc(W, (size_t)3 * B * inp_c); X_bc = dalloc(W, (size_t)B * inp_b); X_eu = dalloc(W, (size_t)B * inp_b);
+        X_c1 = dalloc(W, (size_t)B * inp_c); X_c2 = dalloc(W, (size_t)B * inp_c); X_ct = dalloc(W, (size_t)B * inp_c);
+        const int ap = pad16(ad);
+        vel = dalloc(W, (size_t)B * ap); w_act = dalloc(W, (size_t)B * ap); tgt = dalloc(W, (size_t)B * ap);
+        w_rew = dalloc(W, B); w_mask = dalloc(W, B);
+        p_os = make_pass(W, NET_OS, 3 * B, X_os, false, false);
+        {   // backward view of the (obs, z) block: own gradient buffers, forward buffers shared with p_os
+            p_os_bwd = p_os;
+            p_os_bwd.M = B;
+            const Net& n = nets[NET_OS];
+            for (int l = 0; l < n.nl(); ++l) p_os_bwd.dz.push_back(dalloc(W, (size_t)B * n.layers[l].out_p));
+            for (int l = 0; l + 1 < n.nl(); ++l) p_os_bwd.dy.push_back(n.layers[l].ln ? dalloc(W, (size_t)B * n.layers[l].out_p) : nullptr);
+        }
+        p_bc = make_pass(W, NET_BC, B, X_bc, true, false);
+        p_eu = make_pass(W, NET_BC, B, X_eu, false, false);
+        for (int e = 0; e < 2; ++e) {
+            p_c1[e] = make_pass(W, NET_C0 + e, B, X_c1, true, false);
+            p_c2[e] = make_pass(W, NET_C0 + e, B, X_c2, true, true);
+            p_ct[e] = make_pass(W, NET_T0 + e, B, X_ct, false, false);
+        }
+        build_step_program(prog_fwdbwd, true);
+        build_opt_program(prog_opt);
+        build_step_program(prog_loss, false);
+        schedule(prog_fwdbwd, W); schedule(prog_opt, W); schedule(prog_loss, W);
+        capture(prog_fwdbwd); capture(prog_opt); capture(prog_loss);
+        launches_per_update = (int64_t)prog_fwdbwd.launches.size() + (int64_t)prog_opt.launches.size();
+        src_valid = false;
+    }
+
+    // ---------------------------------------------------------------------------------------
+    // inputs
+    // ---------------------------------------------------------------------------------------
+    static bool is_device_ptr(const void* p) {
+        hipPointerAttribute_t a;
+        hipError_t e = hipPointerGetAttributes(&a, p);
+        if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+        return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged || a.type == hipMemoryTypeUnified;
+    }
+    bool staged_host = false;
+    // host memory is borrowed for the call only: drain the staging copies before returning
+    void drain_staging(hipStream_t s) {
+        if (staged_host) { HIP_CHECK(hipStreamSynchronize(s)); staged_host = false; }
+    }
+    const float* stage(const float* p, float* staging, size_t n, hipStream_t s) {
+        if (!p) return nullptr;
+        if (is_device_ptr(p)) return p;
+        HIP_CHECK(hipMemcpyAsync(staging, p, n * sizeof(float), hipMemcpyHostToDevice, s));
+        staged_host = true;
+        return staging;
+    }
+    void set_source(const SrcDesc& d, hipStream_t s) {
+        if (src_valid && std::memcmp(&d, &h_src_shadow, sizeof d) == 0) return;
+        SrcDesc* slot = &h_src_ring[src_ring_pos];
+        src_ring_pos = (src_ring_pos + 1) % 64;
+        *slot = d;
+        HIP_CHECK(hipMemcpyAsync(d_src, slot, sizeof d, hipMemcpyHostToDevice, s));
+        h_src_shadow = d;
+        src_valid = true;
+    }
+    void source_from_batch(const float* obs, const float* act, const float* rew, const float* mask, const float* nobs,
+                           int batch, const fql_noise* nz, int advance, hipStream_t s) {
+        if (batch != B) invalid("batch_size %d does not match the engine's workspace (%d); call fql_set_batch_size", batch, B);
+        if (!obs || !act || !rew || !mask || !nobs) invalid("batch pointers must not be NULL");
+        const int od = cfg.obs_dim, ad = cfg.act_dim;
+        SrcDesc d{};
+        d.obs = stage(obs, in_obs, (size_t)B * od, s);
+        d.act = stage(act, in_act, (size_t)B * ad, s);
+        d.rew = stage(rew, in_rew, B, s);
+        d.mask = stage(mask, in_mask, B, s);
+        d.nobs = stage(nobs, in_nobs, (size_t)B * od, s);
+        fill_noise(d, nz, s);
+        d.advance = advance;
+        drain_staging(s);
+        set_source(d, s);
+    }
+    void fill_noise(SrcDesc& d, const fql_noise* nz, hipStream_t s) {
+        const int ad = cfg.act_dim;
+        if (!nz) return;
+        d.eps1 = stage(nz->eps1, in_noise[0], (size_t)B * ad, s);
+        d.x0 = stage(nz->x0, in_noise[1], (size_t)B * ad, s);
+        d.t = stage(nz->t, in_noise[2], B, s);
+        d.z = stage(nz->z, in_noise[3], (size_t)B * ad, s);
+        d.eps2 = stage(nz->eps2, in_noise[4], (size_t)B * ad, s);
+    }
+    void source_from_dataset(const int64_t* idx, int batch, int64_t lo, int64_t hi, const fql_noise* nz, hipStream_t s) {
+        if (batch != B) invalid("batch_size %d does not match the engine's workspace (%d)", batch, B);
+        if (!ds_obs || ds_size <= 0) throw Invalid{"no dataset uploaded (fql_dataset_upload)"};
+        if (lo == 0 && hi == 0) hi = ds_size;
+        if (lo < 0 || hi > ds_size || lo >= hi) invalid("bad sampling range [%lld, %lld) for dataset of %lld rows", (long long)lo, (long long)hi, (long long)ds_size);
+        SrcDesc d{};
+        d.obs = ds_obs; d.act = ds_act; d.rew = ds_rew; d.mask = ds_mask; d.nobs = ds_nobs;
+        if (idx) {
+            if (is_device_ptr(idx)) d.idx = idx;
+            else {
+                HIP_CHECK(hipMemcpyAsync(in_idx, idx, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, s));
+                staged_host = true;
+                d.idx = in_idx;
+            }
+        } else {
+            d.use_rng_idx = 1; d.lo = lo; d.span = hi - lo;
+        }
+        fill_noise(d, nz, s);
+        d.advance = 1;
+        drain_staging(s);
+        set_source(d, s);
+    }
+    void finish_info(float* info, int n, hipStream_t s) {
+        if (!info) return;
+        if (is_device_ptr(info)) {
+            HIP_CHECK(hipMemcpyAsync(info, &d_state->info[0], n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        } else {
+            HIP_CHECK(hipMemcpyAsync(info, &d_state->info[0], n * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+        }
+    }
+
+    // ---------------------------------------------------------------------------------------
+    // eval paths
+    // ---------------------------------------------------------------------------------------
+    Eval& get_eval(int n_pad) {
+        auto it = evals.find(n_pad);
+        if (it != evals.end()) return *it->second;
+        auto ev = std::make_unique<Eval>();
+        ev->n_pad = n_pad;
+        auto& W = ev->allocs;
+        const int od = cfg.obs_dim, ad = cfg.act_dim;
+        ev->X = dalloc(W, (size_t)n_pad * nets[NET_OS].in_p());
+        ev->Xf = dalloc(W, (size_t)n_pad * nets[NET_BC].in_p());
+        ev->tgt = dalloc(W, (size_t)n_pad * pad16(ad));
+        ev->st_obs = dalloc(W, (size_t)n_pad * od);
+        ev->st_noise = dalloc(W, (size_t)n_pad * ad);
+        ev->st_out = dalloc(W, (size_t)n_pad * ad);
+        ev->p_os = make_pass(W, NET_OS, n_pad, ev->X, false, false);
+        ev->p_eu = make_pass(W, NET_BC, n_pad, ev->Xf, false, false);
+        emit_forward(ev->prog_os, ev->p_os, false, GF_CLIP_OUT);
+        const int fs = cfg.flow_steps;
+        for (int s = 0; s < fs; ++s)
+            emit_forward(ev->prog_flow, ev->p_eu, false, GF_EULER | (s == fs - 1 ? GF_EULER_LAST : 0), ev->Xf, ev->tgt,
+                         1.0f / (float)fs, (float)(s + 1) / (float)fs);
+        schedule(ev->prog_os, W);
+        schedule(ev->prog_flow, W);
+        Eval& ref = *ev;
+        evals[n_pad] = std::move(ev);
+        return ref;
+    }
+    void eval_rows(bool flow, const float* obs, const float* noise, uint64_t sd, int n, float* out, hipStream_t s) {
+        if (n <= 0) invalid("n must be positive (got %d)", n);
+        if (!obs || !out) invalid("observations/out must not be NULL");
+        if (flow && !noise) invalid("noises must not be NULL");
+        const int od = cfg.obs_dim, ad = cfg.act_dim;
+        const int chunk_cap = 4096;
+        for (int start = 0; start < n; start += chunk_cap) {
+            const int m = std::min(chunk_cap, n - start);
+            Eval& ev = get_eval(pad16(m));
+            const float* o = stage(obs + (size_t)start * od, ev.st_obs, (size_t)m * od, s);
+            const float* z = noise ? stage(noise + (size_t)start * ad, ev.st_noise, (size_t)m * ad, s) : nullptr;
+            drain_staging(s);
+            AssembleArgs a{o, z, flow ? ev.Xf : ev.X, seed, sd + (uint64_t)start, m, ev.n_pad, od, ad,
+                           flow ? nets[NET_BC].in_p() : nets[NET_OS].in_p()};
+            hipLaunchKernelGGL(fql_assemble_kernel, dim3((ev.n_pad + 3) / 4), dim3(FQL_THREADS), 0, s, a);
+            run_launches(flow ? ev.prog_flow : ev.prog_os, s);
+            float* dst = out + (size_t)start * ad;
+            const bool dev_out = is_device_ptr(dst);
+            const float* src16 = flow ? ev.tgt : ev.p_os.out;
+            hipLaunchKernelGGL(fql_extract_kernel, dim3((m * ad + 255) / 256), dim3(256), 0, s, src16, dev_out ? dst : ev.st_out, m, ad, pad16(ad));
+            HIP_CHECK(hipGetLastError());
+            if (!dev_out) {
+                HIP_CHECK(hipMemcpyAsync(dst, ev.st_out, (size_t)m * ad * sizeof(float), hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+            }
+        }
+    }
+};
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+#define FQL_TRY(h, ...)                                    \
+    try {                                                  \
+        __VA_ARGS__;                                       \
+        return FQL_OK;                                     \
+    } catch (const Invalid& e) {                           \
+        (h)->err = e.msg;                                  \
+        return FQL_E_INVALID;                              \
+    } catch (const HipError& e) {                          \
+        (h)->err = e.msg;                                  \
+        return FQL_E_HIP;                                  \
+    } catch (const std::exception& e) {                    \
+        (h)->err = e.what();                               \
+        return FQL_E_HIP;                                  \
+    }
+
+static const char* k_info_names[FQL_NUM_INFO] = {
+    "critic/critic_loss", "critic/q_mean", "critic/q_max", "critic/q_min", "actor/actor_loss",
+    "actor/bc_flow_loss", "actor/distill_loss", "actor/q_loss", "actor/q", "actor/mse",
+    "grad/max", "grad/min", "grad/norm"};
+
+extern "C" {
+
+const char* fql_info_name(int i) { return (i >= 0 && i < FQL_NUM_INFO) ? k_info_names[i] : ""; }
+int fql_abi_version(void) { return FQL_ABI_VERSION; }
+
+void fql_default_config(fql_config* c) {
+    std::memset(c, 0, sizeof *c);
+    c->num_actor_hidden = 4; c->num_value_hidden = 4;
+    for (int i = 0; i < 4; ++i) c->actor_hidden[i] = c->value_hidden[i] = 512;
+    c->layer_norm = 1; c->actor_layer_norm = 0;
+    c->lr = 3e-4f; c->discount = 0.99f; c->tau = 0.005f; c->alpha = 300.0f;
+    c->q_agg = 0; c->flow_steps = 10; c->normalize_q_loss = 0; c->batch_size = 256; c->precision = 0;
+}
+
+const char* fql_last_error(fql_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int fql_create(const fql_config* cfg, uint64_t seed, fql_handle* out) {
+    if (!cfg || !out) { g_create_error = "cfg/out must not be NULL"; return FQL_E_INVALID; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        g_create_error = "no HIP device visible: the FQL engine has no CPU fallback";
+        return FQL_E_NODEVICE;
+    }
+    auto* h = new fql_engine();
+    try {
+        h->cfg = *cfg;
+        h->seed = seed;
+        if (cfg->obs_dim <= 0 || cfg->act_dim <= 0) invalid("obs_dim and act_dim must be positive (got %d, %d)", cfg->obs_dim, cfg->act_dim);
+        if (cfg->num_actor_hidden < 1 || cfg->num_actor_hidden > FQL_MAX_HIDDEN || cfg->num_value_hidden < 1 || cfg->num_value_hidden > FQL_MAX_HIDDEN)
+            invalid("hidden layer counts must be in [1, %d]", FQL_MAX_HIDDEN);
+        if (cfg->flow_steps < 1) invalid("flow_steps must be >= 1");
+        if (cfg->q_agg != 0 && cfg->q_agg != 1) invalid("q_agg must be 0 (mean) or 1 (min)");
+        if (cfg->precision != 0) invalid("precision %d not available (0 = fp32 MFMA)", cfg->precision);
+        HIP_CHECK(hipGetDevice(&h->device));
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, h->device));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            g_create_error = std::string("device is ") + prop.gcnArchName + ", this build targets gfx950 (MI355X) only";
+            delete h;
+            return FQL_E_NODEVICE;
+        }
+        HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->build_nets();
+        HIP_CHECK(hipMalloc((void**)&h->P, h->n_total * sizeof(float)));
+        HIP_CHECK(hipMalloc((void**)&h->G, h->n_train * sizeof(float)));
+        HIP_CHECK(hipMalloc((void**)&h->Mu, h->n_train * sizeof(float)));
+        HIP_CHECK(hipMalloc((void**)&h->Nu, h->n_train * sizeof(float)));
+        HIP_CHECK(hipMemset(h->G, 0, h->n_train * sizeof(float)));
+        HIP_CHECK(hipMemset(h->Mu, 0, h->n_train * sizeof(float)));
+        HIP_CHECK(hipMemset(h->Nu, 0, h->n_train * sizeof(float)));
+        h->build_leaves();
+        h->init_params();
+        HIP_CHECK(hipMalloc((void**)&h->d_state, sizeof(DevState)));
+        HIP_CHECK(hipMalloc((void**)&h->d_src, sizeof(SrcDesc)));
+        HIP_CHECK(hipHostMalloc((void**)&h->h_src_ring, 64 * sizeof(SrcDesc), hipHostMallocDefault));
+        DevState st{};
+        st.rng_step = 0; st.adam_count = 0; st.train_step = 1; st.b1pow = 1.0; st.b2pow = 1.0; st.grad_scale = 1.0f; st.lam = 1.0f;
+        const float ninf = -INFINITY, pinf = INFINITY;
+        int bi; std::memcpy(&bi, &ninf, 4); st.gmax = bi >= 0 ? bi : bi ^ 0x7FFFFFFF;
+        std::memcpy(&bi, &pinf, 4); st.gmin = bi >= 0 ? bi : bi ^ 0x7FFFFFFF;
+        HIP_CHECK(hipMemcpy(h->d_state, &st, sizeof st, hipMemcpyHostToDevice));
+        h->build_workspace(cfg->batch_size);
+    } catch (const Invalid& e) {
+        g_create_error = e.msg; fql_destroy(h); return FQL_E_INVALID;
+    } catch (const HipError& e) {
+        g_create_error = e.msg; fql_destroy(h); return FQL_E_HIP;
+    }
+    *out = h;
+    return FQL_OK;
+}
+
+int fql_destroy(fql_handle h) {
+    if (!h) return FQL_OK;
+    if (h->stream) hipStreamSynchronize(h->stream);
+    hipDeviceSynchronize();
+    h->free_workspace();
+    for (auto& kv : h->evals) {
+        for (void* p : kv.second->allocs) hipFree(p);
+    }
+    hipFree(h->P); hipFree(h->G); hipFree(h->Mu); hipFree(h->Nu); hipFree(h->d_chunks); hipFree(h->d_state); hipFree(h->d_src);
+    if (h->h_src_ring) hipHostFree(h->h_src_ring);
+    hipFree(h->ds_obs); hipFree(h->ds_act); hipFree(h->ds_rew); hipFree(h->ds_mask); hipFree(h->ds_nobs); hipFree(h->ds_row);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return FQL_OK;
+}
+
+int fql_set_batch_size(fql_handle h, int batch_size) {
+    if (!h) return FQL_E_INVALID;
+    FQL_TRY(h, { if (batch_size != h->B) h->build_workspace(batch_size); });
+}
+
+int fql_num_leaves(fql_handle h) { return h ? (int)h->leaves.size() : FQL_E_INVALID; }
+
+int fql_leaf_info(fql_handle h, int index, char* name, int name_cap, int* ndim, int64_t shape[4]) {
+    if (!h) return FQL_E_INVALID;
+    FQL_TRY(h, {
+        if (index < 0 || index >= (int)h->leaves.size()) invalid("leaf index %d out of range", index);
+        const Leaf& l = h->leaves[index];
+        if (name && name_cap > 0) { std::strncpy(name, l.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+        if (ndim) *ndim = l.ndim;
+        if (shape) for (int i = 0; i < 4; ++i) shape[i] = l.shape[i];
+    });
+}
+
+static int leaf_rw(fql_handle h, const char* leaf, float* host, size_t n, int which, bool to_device) {
+    if (!h) return FQL_E_INVALID;
+    try {
+        if (!leaf || !host) invalid("leaf/host pointer must not be NULL");
+        const Leaf* l = h->find_leaf(leaf);
+        if (!l) { h->err = std::string("unknown leaf: ") + leaf; return FQL_E_NOTFOUND; }
+        if (n != fql_engine::leaf_count(*l)) invalid("leaf %s has %zu elements, got %zu", leaf, fql_engine::leaf_count(*l), n);
+        float* arena = h->P;
+        if (which >= 0) {
+            if (!l->trainable && which >= 0) {
+                // optax keeps (zero-gradient) moments for the target leaves too; they stay exactly 0
+                if (to_device) return FQL_OK;
+                std::memset(host, 0, n * sizeof(float));
+                return FQL_OK;
+            }
+            arena = which == 0 ? h->Mu : h->Nu;
+        }
+        h->leaf_io(*l, arena, host, to_device);
+        return FQL_OK;
+    } catch (const Invalid& e) { h->err = e.msg; return FQL_E_INVALID; }
+    catch (const HipError& e) { h->err = e.msg; return FQL_E_HIP; }
+}
+int fql_get_param(fql_handle h, const char* leaf, float* out, size_t n) { return leaf_rw(h, leaf, out, n, -1, false); }
+int fql_set_param(fql_handle h, const char* leaf, const float* in, size_t n) { return leaf_rw(h, leaf, const_cast<float*>(in), n, -1, true); }
+int fql_get_opt_state(fql_handle h, int which, const char* leaf, float* out, size_t n) {
+    if (which != 0 && which != 1) return FQL_E_INVALID;
+    return leaf_rw(h, leaf, out, n, which, false);
+}
+int fql_set_opt_state(fql_handle h, int which, const char* leaf, const float* in, size_t n) {
+    if (which != 0 && which != 1) return FQL_E_INVALID;
+    return leaf_rw(h, leaf, const_cast<float*>(in), n, which, true);
+}
+
+int fql_get_step(fql_handle h, int64_t* adam_count, int64_t* train_step) {
+    if (!h) return FQL_E_INVALID;
+    FQL_TRY(h, {
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        HIP_CHECK(hipDeviceSynchronize());
+        DevState st;
+        HIP_CHECK(hipMemcpy(&st, h->d_state, sizeof st, hipMemcpyDeviceToHost));
+        if (adam_count) *adam_count = st.adam_count;
+        if (train_step) *train_step = st.train_step;
+    });
+}
+int fql_set_step(fql_handle h, int64_t adam_count, int64_t train_step) {
+    if (!h) return FQL_E_INVALID;
+    FQL_TRY(h, {
+        if (adam_count < 0) invalid("adam_count must be >= 0");
+        HIP_CHECK(hipDeviceSynchronize());
+        DevState st;
+        HIP_CHECK(hipMemcpy(&st, h->d_state, sizeof st, hipMemcpyDeviceToHost));
+        st.adam_count = adam_count; st.train_step = train_step;
+        st.b1pow = std::pow(0.9, (double)adam_count); st.b2pow = std::pow(0.999, (double)adam_count);
+        HIP_CHECK(hipMemcpy(h->d_state, &st, sizeof st, hipMemcpyHostToDevice));
+    });
+}
+
+static hipStream_t pick(fql_handle h, void* s) { return s ? (hipStream_t)s : h->stream; }
+
+int fql_update_begin(fql_handle h, const float* obs, const float* act, const float* rew, const float* mask,
+                     const float* nobs, int batch_size, const fql_noise* noise, void* stream) {
+    if (!h) return FQL_E_INVALID;
+    FQL_TRY(h, {
+        hipStream_t s = pick(h, stream);
+        h->source_from_batch(obs, act, rew, mask, nobs, batch_size, noise, 1, s);
+        HIP_CHECK(hipGraphLaunch(h->prog_fwdbwd.exec, s));
+        h->began = true;
+    });
+}
+int fql_update_end(fql_handle h, float* info13, void* stream) {
+    if (!h) return FQL_E_INVALID;
+    if (!h->began) { h->err = "fql_update_end without fql_update_begin"; return FQL_E_STATE; }
+    FQL_TRY(h, {
+        hipStream_t s = pick(h, stream);
+        HIP_CHECK(hipGraphLaunch(h->prog_opt.exec, s));
+        h->began = false;
+        h->finish_info(info13, FQL_NUM_INFO, s);
+    });
+}
+int fql_update(fql_handle h, const float* obs, const float* act, const float* rew, const float* mask, const float* nobs,
+               int batch_size, const fql_noise* noise, float* info13, void* stream) {
+    int rc = fql_update_begin(h, obs, act, rew, mask, nobs, batch_size, noise, stream);
+    if (rc != FQL_OK) return rc;
+    return fql_update_end(h, info13, stream);
+}
+int fql_grad_buffer(fql_handle h, void** device_ptr, size_t* num_floats) {
+    if (!h || !device_ptr || !num_floats) return FQL_E_INVALID;
+    *device_ptr = h->G;
+    *num_floats = h->n_train;
+    return FQL_OK;
+}
+int fql_set_grad_scale(fql_handle h, float scale) {
+    if (!h) return FQL_E_INVALID;
+    FQL_TRY(h, {
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(&h->d_state->grad_scale, &scale, sizeof scale, hipMemcpyHostToDevice));
+    });
+}
+
+int fql_total_loss(fql_handle h, const float* obs, const float* act, const float* rew, const float* mask, const float* nobs,
+                   int batch_size, const fql_noise* noise, float* loss, float* info10, void* stream) {
+    if (!h) return FQL_E_INVALID;
+    FQL_TRY(h, {
+        hipStream_t s = pick(h, stream);
+        h->source_from_batch(obs, act, rew, mask, nobs, batch_size, noise, 0, s);
+        HIP_CHECK(hipGraphLaunch(h->prog_loss.exec, s));
+        float tmp[10];
+        HIP_CHECK(hipMemcpyAsync(tmp, &h->d_state->info[0], sizeof tmp, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (loss) *loss = tmp[0] + tmp[4];
+        if (info10) std::memcpy(info10, tmp, sizeof tmp);
+    });
+}
+
+int fql_sample_actions(fql_handle h, const float* obs, int n, const float* noise, uint64_t seed, float* out, void* stream) {
+    if (!h) return FQL_E_INVALID;
+    FQL_TRY(h, h->eval_rows(false, obs, noise, seed, n, out, pick(h, stream)));
+}
+int fql_flow_actions(fql_handle h, const float* obs, const float* noises, int n, float* out, void* stream) {
+    if (!h) return FQL_E_INVALID;
+    FQL_TRY(h, h->eval_rows(true, obs, noises, 0, n, out, pick(h, stream)));
+}
+
+int fql_dataset_upload(fql_handle h, int64_t n, int64_t capacity, const float* obs, const float* act, const float* rew,
+                       const float* mask, const float* nobs) {
+    if (!h) return FQL_E_INVALID;
+    FQL_TRY(h, {
+        if (n < 0 || capacity < std::max<int64_t>(n, 1)) invalid("need capacity >= max(n, 1) (n=%lld capacity=%lld)", (long long)n, (long long)capacity);
+        if (n > 0 && (!obs || !act || !rew || !mask || !nobs)) invalid("dataset pointers must not be NULL");
+        HIP_CHECK(hipDeviceSynchronize());
+        hipFree(h->ds_obs); hipFree(h->ds_act); hipFree(h->ds_rew); hipFree(h->ds_mask); hipFree(h->ds_nobs);
+        h->ds_obs = h->ds_act = h->ds_rew = h->ds_mask = h->ds_nobs = nullptr;
+        const int od = h->cfg.obs_dim, ad = h->cfg.act_dim;
+        auto up = [&](float*& dst, const float* src, size_t w) {
+            HIP_CHECK(hipMalloc((void**)&dst, (size_t)capacity * w * sizeof(float)));
+            HIP_CHECK(hipMemset(dst, 0, (size_t)capacity * w * sizeof(float)));
+            if (n > 0) HIP_CHECK(hipMemcpy(dst, src, (size_t)n * w * sizeof(float), hipMemcpyDefault));
+        };
+        up(h->ds_obs, obs, od); up(h->ds_act, act, ad); up(h->ds_rew, rew, 1); up(h->ds_mask, mask, 1); up(h->ds_nobs, nobs, od);
+        if (!h->ds_row) HIP_CHECK(hipMalloc((void**)&h->ds_row, (size_t)(2 * od + ad + 2) * sizeof(float)));
+        h->ds_size = n; h->ds_cap = capacity; h->ds_ptr = n % capacity;
+        h->src_valid = false;
+    });
+}
+int fql_dataset_add(fql_handle h, const float* ob, const float* ac, float reward, float mask, const float* nob) {
+    if (!h) return FQL_E_INVALID;
+    FQL_TRY(h, {
+        if (!h->ds_obs) throw Invalid{"no dataset allocated (fql_dataset_upload)"};
+        if (!ob || !ac || !nob) invalid("transition pointers must not be NULL");
+        const int od = h->cfg.obs_dim, ad = h->cfg.act_dim;
+        if (od > 1024) invalid("obs_dim too large for the ring-insert kernel");
+        std::vector<float> row(2 * od + ad + 2);
+        std::memcpy(row.data(), ob, od * sizeof(float));
+        std::memcpy(row.data() + od, ac, ad * sizeof(float));
+        row[od + ad] = reward; row[od + ad + 1] = mask;
+        std::memcpy(row.data() + od + ad + 2, nob, od * sizeof(float));
+        HIP_CHECK(hipMemcpyAsync(h->ds_row, row.data(), row.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(fql_dataset_add_kernel, dim3(1), dim3(std::max(64, pad16(std::max(od, ad)))), 0, h->stream, h->ds_obs,
+                           h->ds_act, h->ds_rew, h->ds_mask, h->ds_nobs, h->ds_row, h->ds_ptr, od, ad);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        // utils/datasets.py:489-491
+        h->ds_ptr = (h->ds_ptr + 1) % h->ds_cap;
+        h->ds_size = std::max(h->ds_ptr, h->ds_size);
+    });
+}
+int fql_dataset_size(fql_handle h, int64_t* size, int64_t* pointer) {
+    if (!h) return FQL_E_INVALID;
+    if (size) *size = h->ds_size;
+    if (pointer) *pointer = h->ds_ptr;
+    return FQL_OK;
+}
+int fql_update_from_dataset_begin(fql_handle h, const int64_t* idx, int batch_size, int64_t lo, int64_t hi,
+                                  const fql_noise* noise, void* stream) {
+    if (!h) return FQL_E_INVALID;
+    FQL_TRY(h, {
+        hipStream_t s = pick(h, stream);
+        h->source_from_dataset(idx, batch_size, lo, hi, noise, s);
+        HIP_CHECK(hipGraphLaunch(h->prog_fwdbwd.exec, s));
+        h->began = true;
+    });
+}
+int fql_update_from_dataset(fql_handle h, const int64_t* idx, int batch_size, int64_t lo, int64_t hi, const fql_noise* noise,
+                            float* info13, void* stream) {
+    int rc = fql_update_from_dataset_begin(h, idx, batch_size, lo, hi, noise, stream);
+    if (rc != FQL_OK) return rc;
+    return fql_update_end(h, info13, stream);
+}
+
+int fql_read_info(fql_handle h, float* info13_host) {
+    if (!h || !info13_host) return FQL_E_INVALID;
+    FQL_TRY(h, {
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(info13_host, &h->d_state->info[0], FQL_NUM_INFO * sizeof(float), hipMemcpyDeviceToHost));
+    });
+}
+
+int fql_stats(fql_handle h, int64_t* launches_per_update, int64_t* macs_per_update, int64_t* param_count) {
+    if (!h) return FQL_E_INVALID;
+    if (launches_per_update) *launches_per_update = h->launches_per_update;
+    if (macs_per_update) *macs_per_update = h->macs_per_update();
+    if (param_count) {
+        int64_t n = 0;
+        for (const Leaf& l : h->leaves) n += (int64_t)fql_engine::leaf_count(l);
+        *param_count = n;
+    }
+    return FQL_OK;
+}
+void* fql_stream(fql_handle h) { return h ? (void*)h->stream : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,747 @@
+// Device code of the FQL step engine, gfx950 (MI355X / CDNA4) only.
+//
+// All dense contractions run on the fp32-input matrix cores (v_mfma_f32_16x16x4_f32): exact fp32
+// products, fp32 accumulate == an fmaf chain, which is what keeps the step inside the fp32 parity
+// tolerance against the CPU oracle.  Feature dimensions are padded to multiples of 16 in HBM (zero
+// padded weights / activations), the batch dimension to multiples of 16.
+//
+// Reference op sites each kernel replaces are cited as file:line of zhouzypaul/fql.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define FQL_THREADS 256
+
+// ------------------------------------------------------------------------------------------------
+// task descriptors (built once on the host, read from HBM by every workgroup of a launch)
+// ------------------------------------------------------------------------------------------------
+enum : int {
+    GF_TRANS_B = 1 << 0,    // B operand is W^T (dgrad):   C = A * W^T,  W stored [K_out=N][..]
+    GF_BIAS = 1 << 1,       // + bias[n]
+    GF_GELU = 1 << 2,       // GELU-tanh epilogue                      utils/networks.py:46,56
+    GF_SAVE_Z = 1 << 3,     // store the pre-activation (needed by GELU' in backward)
+    GF_A_LN = 1 << 4,       // LayerNorm the A tile in LDS before the product   utils/networks.py:58
+    GF_LN_WRITE = 1 << 5,   // column-tile 0 also stores LN(A) and (mean, rstd) for backward
+    GF_GELUGRAD = 1 << 6,   // epilogue: C = acc * GELU'(Zprev)  (dgrad through an un-normalised layer)
+    GF_EULER = 1 << 7,      // epilogue: a += v / flow_steps, t column := t_next    agents/fql.py:166-169
+    GF_EULER_LAST = 1 << 8, // ... and store clip(a, -1, 1) as the distillation target  agents/fql.py:170
+    GF_CLIP_OUT = 1 << 9,   // epilogue: C = clip(acc + bias, -1, 1)            agents/fql.py:152
+};
+
+struct GemmTask {
+    const float* A;     // [M, K] lda
+    const float* B;     // W: [K, N] ldb (or [N.., K..] read transposed with GF_TRANS_B)
+    const float* bias;  // [N]
+    float* C;           // [M, N] ldc
+    float* Zout;        // [M, N] ldc   (GF_SAVE_Z)
+    const float* Zprev; // [M, N] ldc   (GF_GELUGRAD)
+    const float* ln_g;  // [K]          (GF_A_LN)
+    const float* ln_b;  // [K]
+    float* ln_xout;     // [M, K] lda   (GF_LN_WRITE)
+    float* ln_stats;    // [M, 2]       (GF_LN_WRITE)
+    float* aux;         // GF_EULER: X_eu [M, ld = i0]
+    float* aux2;        // GF_EULER_LAST: target actions [M, 16]
+    int M, N, K;
+    int lda, ldb, ldc;
+    int ln_width;       // real (unpadded) width for LN statistics
+    int flags;
+    int tile0;          // first workgroup index of this task inside the launch
+    int ntn;            // workgroup tiles along N
+    int i0, i1, i2;     // GF_EULER: ld of aux, column offset of the action block, act_dim
+    float f0, f1;       // GF_EULER: 1/flow_steps, t_next
+};
+
+struct WgradTask {
+    const float* X;   // [M, Kin] ldx  (layer input)
+    const float* dZ;  // [M, N]   ldz
+    float* dW;        // [Kin, N] ldw
+    float* db;        // [N] or null
+    int M, Kin, N;
+    int ldx, ldz, ldw;
+    int tile0, ntn;
+};
+
+struct LnBwdTask {
+    const float* dY;     // [M, H] ld   gradient w.r.t. LN output
+    const float* Z;      // [M, H] ld   pre-activation of the layer (g = gelu(z) is what LN normalised)
+    const float* stats;  // [M, 2] mean, rstd
+    const float* gamma;  // [H]
+    float* dZ;           // [M, H] ld   out: gradient w.r.t. the pre-activation
+    float* dgamma;       // [H] or null (param grads; column sums over the batch)
+    float* dbeta;        // [H] or null
+    int M, H, ld, width;
+    int tile0, ntiles_rows; // row tasks first, then column-sum tiles
+};
+
+// ------------------------------------------------------------------------------------------------
+// math helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) {
+    // flax nn.gelu (approximate=True): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    const float th = tanhf(u);
+    const float du = 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
+    return 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * du;
+}
+__device__ __forceinline__ float clip1(float x) { return fminf(fmaxf(x, -1.0f), 1.0f); }
+
+// Philox4x32-10 (Salmon et al. 2011), counter-based: the engine's own RNG stream (the reference's
+// threefry stream is not reproducible here).
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                           uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float u32_to_unit(uint32_t x) {  // [0, 1)
+    return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+// element `col` of a standard-normal row vector identified by (key, step, tensor, row)
+__device__ __forceinline__ float rng_normal(uint64_t key, uint64_t step, uint32_t tensor, uint32_t row,
+                                            uint32_t col) {
+    uint32_t r[4];
+    philox4x32((uint32_t)step, (uint32_t)(step >> 32) ^ (tensor << 24), row, col >> 2, (uint32_t)key,
+               (uint32_t)(key >> 32), r);
+    // two Box-Muller pairs per Philox block: (r0, r1) -> cols 4j, 4j+1 ; (r2, r3) -> 4j+2, 4j+3
+    const int pair = (col >> 1) & 1;
+    const float u1 = ((float)(r[2 * pair] >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+    const float u2 = u32_to_unit(r[2 * pair + 1]);
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float s, c;
+    sincosf(6.283185307179586f * u2, &s, &c);
+    return (col & 1) ? rad * s : rad * c;
+}
+__device__ __forceinline__ float rng_uniform(uint64_t key, uint64_t step, uint32_t tensor, uint32_t row) {
+    uint32_t r[4];
+    philox4x32((uint32_t)step, (uint32_t)(step >> 32) ^ (tensor << 24), row, 0u, (uint32_t)key,
+               (uint32_t)(key >> 32), r);
+    return u32_to_unit(r[0]);
+}
+__device__ __forceinline__ uint32_t rng_u32(uint64_t key, uint64_t step, uint32_t tensor, uint32_t row) {
+    uint32_t r[4];
+    philox4x32((uint32_t)step, (uint32_t)(step >> 32) ^ (tensor << 24), row, 0u, (uint32_t)key,
+               (uint32_t)(key >> 32), r);
+    return r[1];
+}
+
+template <typename T>
+__device__ __forceinline__ int find_task(const T* tasks, int ntasks, int b) {
+    int t = 0;
+    for (int i = 1; i < ntasks; ++i)
+        if (b >= tasks[i].tile0) t = i;
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1-K6: Dense (+bias) (+GELU) with optional LayerNorm prologue on the A tile; also dgrad (C = A W^T)
+//   utils/networks.py:53-58 (Dense -> GELU -> LN), agents/fql.py:166-170 (Euler epilogue)
+//
+// Workgroup = 4 waves, output tile 16 rows x 64 columns (one 16x16 MFMA tile per wave, full K).
+// The A tile [16 x K] is staged in LDS (row stride K+4 floats) by coalesced 16-byte loads; with
+// GF_A_LN the 16 rows are normalised in place first (the row statistics need the whole row, which is
+// exactly the K extent of the tile).  K order inside the fma chain: lane (r, q) takes
+// k = 16 j + 4 q + s for MFMA step s of group j, so its A fragment is one ds_read_b128.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FQL_THREADS) void fql_gemm16_kernel(const GemmTask* __restrict__ tasks, int ntasks) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int ti = find_task(tasks, ntasks, blockIdx.x);
+    const GemmTask& T = tasks[ti];
+    const int local = blockIdx.x - T.tile0;
+    const int tm = local / T.ntn, tn = local - tm * T.ntn;
+    const int row0 = tm * 16;
+    const int K = T.K, N = T.N;
+    const int S = K + 4;  // LDS row stride (floats)
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int flags = T.flags;
+
+    // ---- stage A tile
+    {
+        const int k4 = K >> 2;
+        const float* __restrict__ Ag = T.A + (size_t)row0 * T.lda;
+        for (int f = tid; f < 16 * k4; f += FQL_THREADS) {
+            const int r = f / k4, kk = f - r * k4;
+            const float4 v = *reinterpret_cast<const float4*>(Ag + (size_t)r * T.lda + 4 * kk);
+            *reinterpret_cast<float4*>(&lds[r * S + 4 * kk]) = v;
+        }
+    }
+    __syncthreads();
+    if (flags & GF_A_LN) {
+        // 16 threads per row; flax LayerNorm: eps 1e-6, var = max(0, E[x^2] - E[x]^2)
+        const int r = tid >> 4, j = tid & 15;
+        const int width = T.ln_width;
+        float s = 0.f, s2 = 0.f;
+        for (int k = j; k < width; k += 16) {
+            const float v = lds[r * S + k];
+            s += v; s2 += v * v;
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            s += __shfl_xor(s, o);
+            s2 += __shfl_xor(s2, o);
+        }
+        const float inv = 1.0f / (float)width;
+        const float mean = s * inv;
+        const float var = fmaxf(0.0f, s2 * inv - mean * mean);
+        const float rstd = 1.0f / sqrtf(var + 1e-6f);
+        const bool wr = (flags & GF_LN_WRITE) && tn == 0;
+        for (int k = j; k < K; k += 16) {
+            float v = 0.f;
+            if (k < width) v = (lds[r * S + k] - mean) * rstd * T.ln_g[k] + T.ln_b[k];
+            lds[r * S + k] = v;
+            if (wr) T.ln_xout[(size_t)(row0 + r) * T.lda + k] = v;
+        }
+        if (wr && j == 0) {
+            T.ln_stats[2 * (row0 + r)] = mean;
+            T.ln_stats[2 * (row0 + r) + 1] = rstd;
+        }
+        __syncthreads();
+    }
+
+    const int n0 = tn * 64 + wave * 16;
+    if (n0 >= N) return;  // no barriers below
+    const int c = lane & 15, q = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ arow = &lds[c * S + 4 * q];  // A row = lane&15
+    if (flags & GF_TRANS_B) {
+        const float* __restrict__ brow = T.B + (size_t)(n0 + c) * T.ldb + 4 * q;
+#pragma unroll 4
+        for (int j = 0; j < K; j += 16) {
+            const float4 a = *reinterpret_cast<const float4*>(arow + j);
+            const float4 b = *reinterpret_cast<const float4*>(brow + j);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+        }
+    } else {
+        const float* __restrict__ bcol = T.B + (size_t)(4 * q) * T.ldb + n0 + c;
+        const size_t ldb = T.ldb;
+#pragma unroll 4
+        for (int j = 0; j < K; j += 16) {
+            const float4 a = *reinterpret_cast<const float4*>(arow + j);
+            const float* bp = bcol + (size_t)j * ldb;
+            const float b0 = bp[0], b1 = bp[ldb], b2 = bp[2 * ldb], b3 = bp[3 * ldb];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b3, acc, 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue. C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
+    const int n = n0 + c;
+    const float bias = (flags & GF_BIAS) ? T.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + 4 * q + i;
+        float v = acc[i] + bias;
+        const size_t o = (size_t)row * T.ldc + n;
+        if (flags & GF_EULER) {
+            // agents/fql.py:166-169: actions = actions + vels / flow_steps ; t = (i+1)/flow_steps
+            float* xr = T.aux + (size_t)row * T.i0 + T.i1;
+            if (n < T.i2) {
+                const float a = xr[n] + v * T.f0;
+                xr[n] = a;
+                if (flags & GF_EULER_LAST) T.aux2[(size_t)row * T.ldc + n] = clip1(a);
+            }
+            if (n == 0) xr[T.i2] = T.f1;
+            continue;
+        }
+        if (flags & GF_SAVE_Z) T.Zout[o] = v;
+        if (flags & GF_GELU) v = gelu_f(v);
+        if (flags & GF_GELUGRAD) v *= gelu_grad_f(T.Zprev[o]);
+        if (flags & GF_CLIP_OUT) v = clip1(v);
+        T.C[o] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9 wgrad: dW[Kin, N] = X^T dZ (contraction over the batch), db[n] = sum_m dZ[m, n]
+//   implied by jax.grad, utils/flax_utils.py:137.  Workgroup tile 16 (Kin) x 64 (N), wave = 16x16.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FQL_THREADS) void fql_wgrad_kernel(const WgradTask* __restrict__ tasks, int ntasks) {
+    const int ti = find_task(tasks, ntasks, blockIdx.x);
+    const WgradTask& T = tasks[ti];
+    const int local = blockIdx.x - T.tile0;
+    const int tk = local / T.ntn, tn = local - tk * T.ntn;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n0 = tn * 64 + wave * 16;
+    if (n0 >= T.N) return;
+    const int c = lane & 15, q = lane >> 4;
+    const int k0 = tk * 16;
+    const float* __restrict__ xp = T.X + (size_t)q * T.ldx + k0 + c;   // A[i = kin][k = m]
+    const float* __restrict__ zp = T.dZ + (size_t)q * T.ldz + n0 + c;  // B[k = m][j = n]
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float bs = 0.f;
+    const size_t sx = (size_t)4 * T.ldx, sz = (size_t)4 * T.ldz;
+#pragma unroll 8
+    for (int m = 0; m < T.M; m += 4) {
+        const float a = *xp, b = *zp;
+        xp += sx; zp += sz;
+        bs += b;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) T.dW[(size_t)(k0 + 4 * q + i) * T.ldw + n0 + c] = acc[i];
+    if (tk == 0 && T.db) {
+        bs += __shfl_xor(bs, 16);
+        bs += __shfl_xor(bs, 32);
+        if (q == 0) T.db[n0 + c] = bs;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward fused with GELU' (critic, utils/networks.py:56-58 reversed):
+//   dxhat = dY*gamma ; dg = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)) ; dZ = dg GELU'(z)
+// row tiles: one wave per row.  Column tiles (param grads): dgamma = sum_m dY xhat, dbeta = sum_m dY,
+// one workgroup per 64 columns, fixed summation order (deterministic).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FQL_THREADS) void fql_lnbwd_kernel(const LnBwdTask* __restrict__ tasks, int ntasks) {
+    __shared__ float red[2][4][64];
+    const int ti = find_task(tasks, ntasks, blockIdx.x);
+    const LnBwdTask& T = tasks[ti];
+    const int local = blockIdx.x - T.tile0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (local < T.ntiles_rows) {
+        const int row = local * 4 + wave;
+        if (row >= T.M) return;
+        const float mean = T.stats[2 * row], rstd = T.stats[2 * row + 1];
+        const float* dy = T.dY + (size_t)row * T.ld;
+        const float* z = T.Z + (size_t)row * T.ld;
+        float s1 = 0.f, s2 = 0.f;
+        for (int k = lane; k < T.width; k += 64) {
+            const float xh = (gelu_f(z[k]) - mean) * rstd;
+            const float d = dy[k] * T.gamma[k];
+            s1 += d; s2 += d * xh;
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            s1 += __shfl_xor(s1, o);
+            s2 += __shfl_xor(s2, o);
+        }
+        const float inv = 1.0f / (float)T.width;
+        const float m1 = s1 * inv, m2 = s2 * inv;
+        float* dz = T.dZ + (size_t)row * T.ld;
+        for (int k = lane; k < T.H; k += 64) {
+            float v = 0.f;
+            if (k < T.width) {
+                const float zz = z[k];
+                const float xh = (gelu_f(zz) - mean) * rstd;
+                const float d = dy[k] * T.gamma[k];
+                v = rstd * (d - m1 - xh * m2) * gelu_grad_f(zz);
+            }
+            dz[k] = v;
+        }
+    } else {
+        const int col = (local - T.ntiles_rows) * 64 + lane;
+        float sg = 0.f, sb = 0.f;
+        if (col < T.width) {
+            for (int m = wave; m < T.M; m += 4) {
+                const float mean = T.stats[2 * m], rstd = T.stats[2 * m + 1];
+                const float d = T.dY[(size_t)m * T.ld + col];
+                const float xh = (gelu_f(T.Z[(size_t)m * T.ld + col]) - mean) * rstd;
+                sg += d * xh; sb += d;
+            }
+        }
+        red[0][wave][lane] = sg; red[1][wave][lane] = sb;
+        __syncthreads();
+        if (wave == 0 && col < T.H) {
+            const float g = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+            const float b = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+            T.dgamma[col] = (col < T.width) ? g : 0.f;
+            T.dbeta[col] = (col < T.width) ? b : 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// step state + batch assembly
+// ------------------------------------------------------------------------------------------------
+struct DevState {
+    uint64_t rng_step;   // advanced once per update (keys the Philox streams)
+    int64_t adam_count;  // optax count
+    int64_t train_step;  // TrainState.step
+    double b1pow, b2pow; // 0.9^count, 0.999^count
+    float grad_scale;    // 1/world for data-parallel mean
+    float lam;           // normalize_q_loss factor of the current step
+    float info[16];      // the 13 info scalars (+ scratch)
+    float gmax_bits_pad; // unused
+    int gmax, gmin;      // ordered-int encodings for atomicMax/Min
+    float leaf_sumsq[64];
+};
+
+struct SrcDesc {  // where the batch comes from; rewritten by the host only when it changes
+    const float *obs, *act, *rew, *mask, *nobs;
+    const int64_t* idx;  // gather indices or null (rows 0..B-1 of the arrays above)
+    const float *eps1, *x0, *t, *z, *eps2;  // null => engine RNG
+    int64_t lo, span;    // RNG index range [lo, lo+span) when idx == null and use_rng_idx
+    int use_rng_idx;
+    int advance;         // 1: this launch advances rng_step/adam bookkeeping (update), 0: loss-only
+};
+
+struct PrepArgs {
+    const SrcDesc* src;
+    DevState* st;
+    uint64_t key;
+    int B, od, ad;
+    int inp_c, inp_b;  // padded input widths: critic/onestep (od+ad), bc_flow (od+ad+1)
+    int ap;            // padded action width (ld of the [B, ap] action-shaped buffers)
+    float *X_os, *X_bc, *X_eu, *X_c1, *X_c2, *X_ct, *vel, *w_rew, *w_mask, *w_act;
+};
+
+// agents/fql.py:52-56 (x_t, vel), :144-150 (noise), utils/datasets.py:64-100 (index draw + gather),
+// utils/networks.py:191,229-231 (concatenate) -- one pass builds every network input of the step.
+__global__ __launch_bounds__(FQL_THREADS) void fql_prep_kernel(PrepArgs P) {
+    const SrcDesc& S = *P.src;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= P.B) return;
+    const uint64_t step = P.st->rng_step;
+    int64_t src = b;
+    if (S.idx) src = S.idx[b];
+    else if (S.use_rng_idx) src = S.lo + (int64_t)(((uint64_t)rng_u32(P.key, step, 7u, (uint32_t)b) * (uint64_t)S.span) >> 32);
+    const int od = P.od, ad = P.ad, B = P.B;
+    const float* obs = S.obs + (size_t)src * od;
+    const float* nobs = S.nobs + (size_t)src * od;
+    const float* act = S.act + (size_t)src * ad;
+    const float tt = S.t ? S.t[b] : rng_uniform(P.key, step, 3u, (uint32_t)b);
+    const int maxw = P.inp_c > P.inp_b ? P.inp_c : P.inp_b;
+    for (int j = lane; j < maxw; j += 64) {
+        const bool is_obs = j < od, is_act = (j >= od) && (j < od + ad);
+        const int a = j - od;
+        float o = 0.f, no = 0.f, av = 0.f, e1 = 0.f, e2 = 0.f, zz = 0.f, xx = 0.f;
+        if (is_obs) { o = obs[j]; no = nobs[j]; }
+        if (is_act) {
+            av = act[a];
+            e1 = S.eps1 ? S.eps1[(size_t)b * ad + a] : rng_normal(P.key, step, 1u, (uint32_t)b, (uint32_t)a);
+            xx = S.x0 ? S.x0[(size_t)b * ad + a] : rng_normal(P.key, step, 2u, (uint32_t)b, (uint32_t)a);
+            zz = S.z ? S.z[(size_t)b * ad + a] : rng_normal(P.key, step, 4u, (uint32_t)b, (uint32_t)a);
+            e2 = S.eps2 ? S.eps2[(size_t)b * ad + a] : rng_normal(P.key, step, 5u, (uint32_t)b, (uint32_t)a);
+        }
+        if (j < P.inp_c) {
+            const size_t w = P.inp_c;
+            P.X_os[(size_t)b * w + j] = is_obs ? no : e1;            // sample_actions(next_obs)  fql.py:25
+            P.X_os[(size_t)(B + b) * w + j] = is_obs ? o : zz;       // onestep(obs, noises)      fql.py:65
+            P.X_os[(size_t)(2 * B + b) * w + j] = is_obs ? o : e2;   // sample_actions(obs)       fql.py:82
+            P.X_c1[(size_t)b * w + j] = is_obs ? o : av;             // critic(obs, actions)      fql.py:36
+            P.X_c2[(size_t)b * w + j] = is_obs ? o : 0.f;            // action block filled after onestep
+            P.X_ct[(size_t)b * w + j] = is_obs ? no : 0.f;
+        }
+        if (j < P.inp_b) {
+            const size_t w = P.inp_b;
+            const float xt = (1.0f - tt) * xx + tt * av;             // fql.py:55
+            P.X_bc[(size_t)b * w + j] = is_obs ? o : (is_act ? xt : (j == od + ad ? tt : 0.f));
+            P.X_eu[(size_t)b * w + j] = is_obs ? o : (is_act ? zz : 0.f);  // t_0 = 0
+        }
+        if (is_act) {
+            P.vel[(size_t)b * P.ap + a] = av - xx;                     // fql.py:56
+            P.w_act[(size_t)b * P.ap + a] = av;
+        }
+    }
+    if (lane == 0) {
+        P.w_rew[b] = S.rew[src];
+        P.w_mask[b] = S.mask[src];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-workgroup loss / bookkeeping kernels (B <= a few thousand rows: latency, not bandwidth)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+struct PostOsArgs {
+    const float* A_os;  // [3B, 16] raw one-step actor outputs
+    const float* w_act; // [B, 16]
+    float *X_ct, *X_c2; // [B, inp_c]
+    DevState* st;
+    int B, od, ad, inp_c, ap;
+};
+// agents/fql.py:26 (clip next actions), :69 (clip actor actions), :82-83 (mse metric)
+__global__ __launch_bounds__(FQL_THREADS) void fql_post_onestep_kernel(PostOsArgs P) {
+    __shared__ float sh[4];
+    float se = 0.f;
+    const int n = P.B * P.ad;
+    for (int e = threadIdx.x; e < n; e += FQL_THREADS) {
+        const int b = e / P.ad, a = e - b * P.ad;
+        P.X_ct[(size_t)b * P.inp_c + P.od + a] = clip1(P.A_os[(size_t)b * P.ap + a]);
+        P.X_c2[(size_t)b * P.inp_c + P.od + a] = clip1(P.A_os[(size_t)(P.B + b) * P.ap + a]);
+        const float d = clip1(P.A_os[(size_t)(2 * P.B + b) * P.ap + a]) - P.w_act[(size_t)b * P.ap + a];
+        se += d * d;
+    }
+    const float tot = block_sum(se, sh);
+    if (threadIdx.x == 0) P.st->info[9] = tot / (float)n;
+}
+
+struct LossCriticArgs {
+    const float *q1a, *q1b, *tqa, *tqb;  // [B,16] column 0
+    const float *w_rew, *w_mask;
+    float *dq1a, *dq1b;                  // [B,16] column 0 (other columns stay zero)
+    DevState* st;
+    int B, q_agg, want_grad;
+    float discount;
+};
+// agents/fql.py:28-44
+__global__ __launch_bounds__(FQL_THREADS) void fql_loss_critic_kernel(LossCriticArgs P) {
+    __shared__ float sh[4];
+    float sl = 0.f, sq = 0.f, mx = -INFINITY, mn = INFINITY;
+    const float gs = 1.0f / (float)P.B;  // d/dq of mean over 2B of (q-y)^2 = 2 (q-y) / (2B)
+    for (int b = threadIdx.x; b < P.B; b += FQL_THREADS) {
+        const float ta = P.tqa[(size_t)b * 16], tb = P.tqb[(size_t)b * 16];
+        const float nq = P.q_agg ? fminf(ta, tb) : 0.5f * (ta + tb);
+        const float y = P.w_rew[b] + P.discount * P.w_mask[b] * nq;
+        const float qa = P.q1a[(size_t)b * 16], qb = P.q1b[(size_t)b * 16];
+        const float da = qa - y, db = qb - y;
+        sl += da * da + db * db;
+        sq += qa + qb;
+        mx = fmaxf(mx, fmaxf(qa, qb));
+        mn = fminf(mn, fminf(qa, qb));
+        if (P.want_grad) {
+            P.dq1a[(size_t)b * 16] = da * gs;
+            P.dq1b[(size_t)b * 16] = db * gs;
+        }
+    }
+    const float tl = block_sum(sl, sh), tq = block_sum(sq, sh);
+    const float tmx = block_max(mx, sh), tmn = -block_max(-mn, sh);
+    if (threadIdx.x == 0) {
+        const float inv = 1.0f / (2.0f * (float)P.B);
+        P.st->info[0] = tl * inv;
+        P.st->info[1] = tq * inv;
+        P.st->info[2] = tmx;
+        P.st->info[3] = tmn;
+    }
+}
+
+struct LossQArgs {
+    const float *q2a, *q2b;  // [B,16] col 0: critic(obs, clip(actor_actions))
+    float *dq2a, *dq2b;
+    DevState* st;
+    int B, normalize, want_grad;
+};
+// agents/fql.py:70-76
+__global__ __launch_bounds__(FQL_THREADS) void fql_loss_q_kernel(LossQArgs P) {
+    __shared__ float sh[4];
+    float s = 0.f, sa = 0.f;
+    for (int b = threadIdx.x; b < P.B; b += FQL_THREADS) {
+        const float q = 0.5f * (P.q2a[(size_t)b * 16] + P.q2b[(size_t)b * 16]);
+        s += q; sa += fabsf(q);
+    }
+    const float ts = block_sum(s, sh), tsa = block_sum(sa, sh);
+    const float qmean = ts / (float)P.B;
+    const float lam = P.normalize ? 1.0f / (tsa / (float)P.B) : 1.0f;
+    if (P.want_grad) {
+        const float g = -lam / (2.0f * (float)P.B);
+        for (int b = threadIdx.x; b < P.B; b += FQL_THREADS) {
+            P.dq2a[(size_t)b * 16] = g;
+            P.dq2b[(size_t)b * 16] = g;
+        }
+    }
+    if (threadIdx.x == 0) {
+        P.st->info[7] = lam * (-qmean);
+        P.st->info[8] = qmean;
+        P.st->lam = lam;
+    }
+}
+
+struct LossBcArgs {
+    const float *pred, *vel;  // [B,16]
+    float* dpred;             // [B,16]
+    DevState* st;
+    int B, ad, ap, want_grad;
+};
+// agents/fql.py:58-59
+__global__ __launch_bounds__(FQL_THREADS) void fql_loss_bc_kernel(LossBcArgs P) {
+    __shared__ float sh[4];
+    const int n = P.B * P.ad;
+    const float gs = 2.0f / (float)n;
+    float s = 0.f;
+    for (int e = threadIdx.x; e < n; e += FQL_THREADS) {
+        const int b = e / P.ad, a = e - b * P.ad;
+        const float d = P.pred[(size_t)b * P.ap + a] - P.vel[(size_t)b * P.ap + a];
+        s += d * d;
+        if (P.want_grad) P.dpred[(size_t)b * P.ap + a] = gs * d;
+    }
+    const float t = block_sum(s, sh);
+    if (threadIdx.x == 0) P.st->info[5] = t / (float)n;
+}
+
+struct LossActorArgs {
+    const float* a_raw;      // [B,16] one-step actor output rows (obs, z)
+    const float* tgt;        // [B,16] clip(Euler(bc_flow))
+    const float *dxa, *dxb;  // [B, inp_c] critic input gradients of the two members (or null)
+    float* da;               // [B,16]
+    DevState* st;
+    int B, od, ad, inp_c, ap, want_grad;
+    float alpha;
+};
+// agents/fql.py:66 (distill), :69-79 (clip mask on the Q path, total actor loss)
+__global__ __launch_bounds__(FQL_THREADS) void fql_loss_actor_kernel(LossActorArgs P) {
+    __shared__ float sh[4];
+    const int n = P.B * P.ad;
+    const float gs = P.alpha * 2.0f / (float)n;
+    float s = 0.f;
+    for (int e = threadIdx.x; e < n; e += FQL_THREADS) {
+        const int b = e / P.ad, a = e - b * P.ad;
+        const float ar = P.a_raw[(size_t)b * P.ap + a];
+        const float d = ar - P.tgt[(size_t)b * P.ap + a];
+        s += d * d;
+        if (P.want_grad) {
+            float g = gs * d;
+            if (ar > -1.0f && ar < 1.0f) {
+                const size_t o = (size_t)b * P.inp_c + P.od + a;
+                g += P.dxa[o] + P.dxb[o];
+            }
+            P.da[(size_t)b * P.ap + a] = g;
+        }
+    }
+    const float t = block_sum(s, sh);
+    if (threadIdx.x == 0) {
+        const float distill = t / (float)n;
+        P.st->info[6] = distill;
+        P.st->info[4] = P.st->info[5] + P.alpha * distill + P.st->info[7];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K10-K12: grad stats + Adam + Polyak in one pass over the trainable arena
+//   utils/flax_utils.py:139-157 (stats), optax.adam (agents/fql.py:237), agents/fql.py:113-120 (Polyak
+//   reads the PRE-step critic: p_old is still in a register when the target is written).
+// ------------------------------------------------------------------------------------------------
+struct AdamChunk { int off, len, leaf; };
+struct AdamArgs {
+    float *P, *G, *Mu, *Nu, *T;  // T = target arena (same layout as the critic block at offset 0)
+    const AdamChunk* chunks;
+    DevState* st;
+    int critic_size;
+    float lr, tau;
+};
+__device__ __forceinline__ int f2ord(float f) {
+    const int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7FFFFFFF;
+}
+__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+
+__global__ __launch_bounds__(FQL_THREADS) void fql_begin_step_kernel(DevState* st, const SrcDesc* src) {
+    // one thread: advance counters (optax count, TrainState.step) and the bias-correction powers
+    if (threadIdx.x == 0 && src->advance) {
+        st->adam_count += 1;
+        st->train_step += 1;
+        st->b1pow *= 0.9;
+        st->b2pow *= 0.999;
+    }
+}
+
+__global__ __launch_bounds__(FQL_THREADS) void fql_adam_kernel(AdamArgs A) {
+    __shared__ float sh[4];
+    const AdamChunk ch = A.chunks[blockIdx.x];
+    const float c1 = (float)(1.0 - A.st->b1pow), c2 = (float)(1.0 - A.st->b2pow);
+    const float gsc = A.st->grad_scale;
+    float ss = 0.f, mx = -INFINITY, mn = INFINITY;
+    for (int i = threadIdx.x; i < ch.len; i += FQL_THREADS) {
+        const int o = ch.off + i;
+        const float g = A.G[o] * gsc;
+        const float p = A.P[o];
+        const float m = 0.9f * A.Mu[o] + 0.1f * g;
+        const float v = 0.999f * A.Nu[o] + 0.001f * g * g;
+        A.Mu[o] = m; A.Nu[o] = v;
+        const float mh = m / c1, vh = v / c2;
+        A.P[o] = p - A.lr * (mh / (sqrtf(vh) + 1e-8f));
+        if (o < A.critic_size) A.T[o] = p * A.tau + A.T[o] * (1.0f - A.tau);
+        ss += g * g; mx = fmaxf(mx, g); mn = fminf(mn, g);
+    }
+    const float tss = block_sum(ss, sh);
+    const float tmx = block_max(mx, sh), tmn = -block_max(-mn, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd(&A.st->leaf_sumsq[ch.leaf], tss);
+        atomicMax(&A.st->gmax, f2ord(tmx));
+        atomicMin(&A.st->gmin, f2ord(tmn));
+    }
+}
+
+__global__ void fql_finalize_kernel(DevState* st, int nleaves, int do_grad_stats) {
+    // grad/norm = sum over leaves of ||g_leaf||_2 (utils/flax_utils.py:141,149); target-critic leaves
+    // contribute zeros, which also bound grad/max >= 0 >= grad/min (F5).
+    if (threadIdx.x == 0) {
+        if (do_grad_stats) {
+            float nrm = 0.f;
+            for (int i = 0; i < nleaves; ++i) {
+                nrm += sqrtf(st->leaf_sumsq[i]);
+                st->leaf_sumsq[i] = 0.f;
+            }
+            st->info[10] = fmaxf(ord2f(st->gmax), 0.0f);
+            st->info[11] = fminf(ord2f(st->gmin), 0.0f);
+            st->info[12] = nrm;
+            st->gmax = f2ord(-INFINITY);
+            st->gmin = f2ord(INFINITY);
+            st->rng_step += 1;
+        }
+    }
+}
+
+// sample_actions / flow_actions input assembly: X[n_pad, inp] = concat(obs, noise[, t=0])
+struct AssembleArgs {
+    const float *obs, *noise;  // noise null => RNG keyed by (key, seed)
+    float* X;
+    uint64_t key, seed;
+    int n, n_pad, od, ad, inp;
+};
+__global__ __launch_bounds__(FQL_THREADS) void fql_assemble_kernel(AssembleArgs P) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= P.n_pad) return;
+    for (int j = lane; j < P.inp; j += 64) {
+        float v = 0.f;
+        if (b < P.n) {
+            if (j < P.od) v = P.obs[(size_t)b * P.od + j];
+            else if (j < P.od + P.ad) {
+                const int a = j - P.od;
+                v = P.noise ? P.noise[(size_t)b * P.ad + a] : rng_normal(P.key, P.seed, 9u, (uint32_t)b, (uint32_t)a);
+            }
+        }
+        P.X[(size_t)b * P.inp + j] = v;
+    }
+}
+// out[n, ad] = src[n, 16][:, :ad]
+__global__ void fql_extract_kernel(const float* src, float* out, int n, int ad, int ap) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n * ad) out[e] = src[(size_t)(e / ad) * ap + (e % ad)];
+}
+// ReplayBuffer.add_transition (utils/datasets.py:483-491): one row into the ring
+__global__ void fql_dataset_add_kernel(float* obs, float* act, float* rew, float* mask, float* nobs,
+                                       const float* row, int64_t pos, int od, int ad) {
+    // row = [obs(od) | act(ad) | reward | mask | next_obs(od)]
+    const int j = threadIdx.x;
+    if (j < od) { obs[pos * od + j] = row[j]; nobs[pos * od + j] = row[od + ad + 2 + j]; }
+    if (j < ad) act[pos * ad + j] = row[od + j];
+    if (j == 0) { rew[pos] = row[od + ad]; mask[pos] = row[od + ad + 1]; }
+}
