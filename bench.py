@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""Headline benchmark: FQL gradient-steps/s at per-GPU batch 256 (BASELINE.json metric).
+
+Workload = BASELINE.json configs[1]: antmaze-large-shaped synthetic offline data (obs=29, act=8),
+batch=256, hidden 512x4, flow_steps=10, alpha=10, 1,000,000 device-resident transitions
+(generator: SURVEY.md 8d), indices and the five noise tensors drawn by the engine's device RNG.
+One "step" = one full FQLAgent.update (forward, backward, grad stats, Adam, Polyak) on one batch.
+
+N > 1 (launched by torch.distributed.run): one process per GPU, replay sharded by transition index,
+gradient all-reduce over RCCL, identical optimizer step on every rank ("scaling": "weak").
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (matrix), v_mfma_f32_16x16x4_f32
+
+
+def cpu_baseline(cfg, od, ad, B, budget_s=20.0):
+    """Times the torch-CPU restatement of the reference update (oracle/, "port") on this host."""
+    import torch
+    from oracle import fql_oracle as O
+    from oracle.fql_oracle_torch import TorchFQL
+    cores = torch.get_num_threads()
+    params = O.init_params(0, od, ad, dict(cfg))
+    ref = TorchFQL(params, dict(cfg), torch.float32)
+    ds = O.make_synthetic_dataset(8192, od, ad, seed=0)
+    rng = np.random.default_rng(1)
+    batches = [(O.sample_batch(ds, rng.integers(0, 8192, size=B)), O.make_noise(B, ad, 10 + i)) for i in range(4)]
+    ref.update(*batches[0])  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        ref.update(*batches[n % 4])
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 200:
+            break
+    return {'value': round(n / dt, 3), 'unit': 'grad-steps/s', 'cores': int(cores), 'kind': 'port',
+            'sample': f'{n} updates of the torch-CPU restatement (oracle/fql_oracle_torch.py, fp32, B={B}) in {dt:.1f}s; '
+                      'CPU restatement of the reference path, not JAX'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3000)
+    ap.add_argument('--warmup', type=int, default=300)
+    ap.add_argument('--batch', type=int, default=256)
+    ap.add_argument('--rows', type=int, default=1_000_000)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import fql_amd
+    from fql_amd.parallel import DataParallelFQL, shard_range
+    from oracle import fql_oracle as O  # synthetic data generator only
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    od, ad, B = 29, 8, args.batch
+    cfg = fql_amd.get_config()
+    cfg.update(alpha=10.0, batch_size=B)
+    ds = O.make_synthetic_dataset(args.rows, od, ad, seed=0)
+    agent = fql_amd.FQLAgent.create(rank, ds['observations'][:1], ds['actions'][:1], cfg)
+    agent.upload_dataset(ds)
+    stream = torch.cuda.current_stream().cuda_stream
+    dp = DataParallelFQL(agent) if world > 1 else None
+    lo, hi = shard_range(args.rows, rank, world)
+
+    def step():
+        if dp is not None:
+            dp.update_from_dataset(args.rows, batch_size=B)
+        else:
+            agent.update_from_dataset(B, stream=stream)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the graphs are launched on
+    info = agent.read_info()
+    st = agent.stats()
+
+    if rank == 0:
+        steps_per_s = args.steps / dt
+        flop_per_step = 2.0 * st['macs_per_update']            # algorithmic: SURVEY.md 8d (12.376 GFLOP at B=256)
+        step_us_dev = dev_ms * 1e3 / args.steps                # device time per update (HIP events)
+        achieved = flop_per_step / (step_us_dev * 1e-6) / 1e12
+        out = {
+            'metric': 'FQL gradient-steps/s (batch=256)', 'value': round(steps_per_s * world, 2), 'unit': 'grad-steps/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt * 1e3 / args.steps, 5),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'antmaze-large-shaped synthetic replay (obs=29, act=8), batch=256/GPU, hidden=512x4, '
+                                   'flow_steps=10, alpha=10, 1M device-resident transitions (BASELINE.json configs[1])',
+                       'parallelism': f'dp{world}', 'samples_per_s': round(steps_per_s * world * B, 1)},
+            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), 'traffic': None,
+                         'kernel': 'whole update graph (MFMA tile kernels fql_gemm16_kernel + fql_wgrad_kernel dominate)',
+                         'flop_per_launch': flop_per_step, 'launch_us': round(step_us_dev, 3),
+                         'kernel_launches_per_update': st['launches_per_update']},
+            'last_info': {k: round(v, 5) for k, v in info.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(cfg, od, ad, B)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
