@@ -82,7 +82,7 @@ def main():
     ds = O.make_synthetic_dataset(args.rows, od, ad, seed=0)
     agent = fql_amd.FQLAgent.create(rank, ds['observations'][:1], ds['actions'][:1], cfg)
     agent.upload_dataset(ds)
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = None if os.environ.get('FQL_BENCH_OWN_STREAM') else torch.cuda.current_stream().cuda_stream
     dp = DataParallelFQL(agent) if world > 1 else None
     lo, hi = shard_range(args.rows, rank, world)
 

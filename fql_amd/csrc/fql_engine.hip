@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -554,10 +555,11 @@ struct fql_engine {
                     std::vector<GemmTask> tb;
                     for (const Op* o : sel) {
                         GemmTask t = o->gemm;
-                        t.ntn = (t.N + 63) / 64;
+                        t.wk = (t.N <= 16) ? 4 : 2;
+                        t.ntn = (t.N / 16 + (4 / t.wk) - 1) / (4 / t.wk);
                         t.tile0 = tile;
                         tile += (t.M / 16) * t.ntn;
-                        L.lds = std::max(L.lds, (size_t)16 * (t.K + 4) * sizeof(float));
+                        L.lds = std::max(L.lds, ((size_t)16 * (t.K + 4) + 1024) * sizeof(float));
                         tb.push_back(t);
                     }
                     L.table = dalloc(owner, tb.size() * sizeof(GemmTask) / sizeof(float) + 4);
@@ -579,7 +581,7 @@ struct fql_engine {
                         LnBwdTask t = o->ln;
                         t.ntiles_rows = (t.M + 3) / 4;
                         t.tile0 = tile;
-                        tile += t.ntiles_rows + (t.dgamma ? (t.H + 63) / 64 : 0);
+                        tile += t.ntiles_rows + (t.dgamma ? t.H / 16 : 0);
                         tb.push_back(t);
                     }
                     L.table = dalloc(owner, tb.size() * sizeof(LnBwdTask) / sizeof(float) + 4);
@@ -1170,13 +1172,19 @@ int fql_set_step(fql_handle h, int64_t adam_count, int64_t train_step) {
 
 static hipStream_t pick(fql_handle h, void* s) { return s ? (hipStream_t)s : h->stream; }
 
+static void run_program(fql_handle h, Program& pr, hipStream_t s) {
+    static const bool no_graph = getenv("FQL_NO_GRAPH") != nullptr;
+    if (no_graph) h->run_launches(pr, s);
+    else HIP_CHECK(hipGraphLaunch(pr.exec, s));
+}
+
 int fql_update_begin(fql_handle h, const float* obs, const float* act, const float* rew, const float* mask,
                      const float* nobs, int batch_size, const fql_noise* noise, void* stream) {
     if (!h) return FQL_E_INVALID;
     FQL_TRY(h, {
         hipStream_t s = pick(h, stream);
         h->source_from_batch(obs, act, rew, mask, nobs, batch_size, noise, 1, s);
-        HIP_CHECK(hipGraphLaunch(h->prog_fwdbwd.exec, s));
+        run_program(h, h->prog_fwdbwd, s);
         h->began = true;
     });
 }
@@ -1185,7 +1193,7 @@ int fql_update_end(fql_handle h, float* info13, void* stream) {
     if (!h->began) { h->err = "fql_update_end without fql_update_begin"; return FQL_E_STATE; }
     FQL_TRY(h, {
         hipStream_t s = pick(h, stream);
-        HIP_CHECK(hipGraphLaunch(h->prog_opt.exec, s));
+        run_program(h, h->prog_opt, s);
         h->began = false;
         h->finish_info(info13, FQL_NUM_INFO, s);
     });
@@ -1216,7 +1224,7 @@ int fql_total_loss(fql_handle h, const float* obs, const float* act, const float
     FQL_TRY(h, {
         hipStream_t s = pick(h, stream);
         h->source_from_batch(obs, act, rew, mask, nobs, batch_size, noise, 0, s);
-        HIP_CHECK(hipGraphLaunch(h->prog_loss.exec, s));
+        run_program(h, h->prog_loss, s);
         float tmp[10];
         HIP_CHECK(hipMemcpyAsync(tmp, &h->d_state->info[0], sizeof tmp, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
@@ -1289,7 +1297,7 @@ int fql_update_from_dataset_begin(fql_handle h, const int64_t* idx, int batch_si
     FQL_TRY(h, {
         hipStream_t s = pick(h, stream);
         h->source_from_dataset(idx, batch_size, lo, hi, noise, s);
-        HIP_CHECK(hipGraphLaunch(h->prog_fwdbwd.exec, s));
+        run_program(h, h->prog_fwdbwd, s);
         h->began = true;
     });
 }

@@ -12,6 +12,15 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Pointers read out of a task table are generic to the compiler and would become flat_load/flat_store
+// (which also tick lgkmcnt and serialise against LDS traffic).  Everything the engine hands to a kernel is
+// device global memory, so say so.
+#define FQL_GAS __attribute__((address_space(1)))
+__device__ __forceinline__ float ldg(const float* p) { return *(const FQL_GAS float*)p; }
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const FQL_GAS f32x4*)p; }
+__device__ __forceinline__ void stg(float* p, float v) { *(FQL_GAS float*)p = v; }
+__device__ __forceinline__ void stg4(float* p, f32x4 v) { *(FQL_GAS f32x4*)p = v; }
+
 #define FQL_THREADS 256
 
 // ------------------------------------------------------------------------------------------------
@@ -49,6 +58,7 @@ struct GemmTask {
     int flags;
     int tile0;          // first workgroup index of this task inside the launch
     int ntn;            // workgroup tiles along N
+    int wk;             // K-split ways among the 4 waves (1, 2 or 4); column tiles per workgroup = 4 / wk
     int i0, i1, i2;     // GF_EULER: ld of aux, column offset of the action block, act_dim
     float f0, f1;       // GF_EULER: 1/flow_steps, t_next
 };
@@ -151,16 +161,106 @@ __device__ __forceinline__ int find_task(const T* tasks, int ntasks, int b) {
 // K1-K6: Dense (+bias) (+GELU) with optional LayerNorm prologue on the A tile; also dgrad (C = A W^T)
 //   utils/networks.py:53-58 (Dense -> GELU -> LN), agents/fql.py:166-170 (Euler epilogue)
 //
-// Workgroup = 4 waves, output tile 16 rows x 64 columns (one 16x16 MFMA tile per wave, full K).
-// The A tile [16 x K] is staged in LDS (row stride K+4 floats) by coalesced 16-byte loads; with
-// GF_A_LN the 16 rows are normalised in place first (the row statistics need the whole row, which is
-// exactly the K extent of the tile).  K order inside the fma chain: lane (r, q) takes
-// k = 16 j + 4 q + s for MFMA step s of group j, so its A fragment is one ds_read_b128.
+// Workgroup = 4 waves on a 16-row tile.  The 4 waves are arranged as NW column tiles x WK K-parts
+// (NW * WK = 4): wide layers use 2 x 2 (16 x 32 output tile, each wave half of K), 16-column layers
+// (the action / Q heads) 1 x 4.  That puts a [256 x 512] x [512 x 512] layer of the sequential Euler
+// chain on 256 workgroups x 4 waves = every SIMD of the chip with 64 MFMAs each; the partial
+// accumulators meet in LDS.  The A tile [16 x K] is staged in LDS (row stride K+4 floats) by coalesced
+// 16-byte loads; with GF_A_LN the 16 rows are normalised in place first (the row statistics need the
+// whole row = the K extent of the tile).  B fragments are prefetched from L2 into registers one
+// 128-deep K chunk (32 VGPRs) ahead of the MFMAs that consume them: at one wave per SIMD nothing
+// else hides the load latency.  K order inside the fma chain: lane (r, q) takes k = 16 g + 4 q + s for
+// MFMA step s of group g, so its A fragment is one ds_read_b128.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(FQL_THREADS) void fql_gemm16_kernel(const GemmTask* __restrict__ tasks, int ntasks) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int ti = find_task(tasks, ntasks, blockIdx.x);
-    const GemmTask& T = tasks[ti];
+template <bool TRANS>
+__device__ __forceinline__ void gemm_load_chunk(float (&b)[32], const float* __restrict__ bp, size_t ldb) {
+    if (TRANS) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 v = ldg4(bp + 16 * g);
+            b[4 * g] = v[0]; b[4 * g + 1] = v[1]; b[4 * g + 2] = v[2]; b[4 * g + 3] = v[3];
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) b[4 * g + s] = ldg(bp + (size_t)(16 * g + s) * ldb);
+    }
+}
+__device__ __forceinline__ void gemm_mma_chunk(f32x4& acc, const float (&b)[32], const float* arow) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const float4 a = *reinterpret_cast<const float4*>(arow + 16 * g);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[4 * g], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[4 * g + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[4 * g + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[4 * g + 3], acc, 0, 0, 0);
+    }
+}
+
+// B-operand addressing of one wave: element (k, n0 + c), k = 16 g + 4 q (+ s)
+struct BAddr {
+    const float* base;
+    size_t ldb, kstep;
+};
+template <bool TRANS>
+__device__ __forceinline__ BAddr gemm_baddr(const GemmTask& T, int n0, int c, int q) {
+    BAddr a;
+    a.ldb = T.ldb;
+    a.base = TRANS ? T.B + (size_t)(n0 + c) * a.ldb + 4 * q : T.B + (size_t)(4 * q) * a.ldb + n0 + c;
+    a.kstep = TRANS ? 1 : a.ldb;
+    return a;
+}
+// b0 / b1 already hold chunks 0 / 1 of [gbeg, gend) when they exist (issued before the A tile landed)
+template <bool TRANS>
+__device__ __forceinline__ f32x4 gemm_wave(const BAddr& ba, const float* lds_a, int S, int gbeg, int gend, int c, int q,
+                                           float (&b0)[32], float (&b1)[32]) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ arow = lds_a + c * S + 4 * q;
+    int g = gbeg;
+    const int nfull = (gend - gbeg) >> 3;
+    for (int i = 0; i < nfull; i += 2) {
+        gemm_mma_chunk(acc, b0, arow + 16 * g);
+        if (i + 2 < nfull) gemm_load_chunk<TRANS>(b0, ba.base + (size_t)(16 * (g + 16)) * ba.kstep, ba.ldb);
+        if (i + 1 < nfull) {
+            gemm_mma_chunk(acc, b1, arow + 16 * (g + 8));
+            if (i + 3 < nfull) gemm_load_chunk<TRANS>(b1, ba.base + (size_t)(16 * (g + 24)) * ba.kstep, ba.ldb);
+        }
+        g += 16;
+    }
+    g = gbeg + 8 * nfull;
+    // tail: < 8 groups, all loads first
+    const int nt = gend - g;
+    if (nt > 0) {
+        float bt[28];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            if (t < nt) {
+                if (TRANS) {
+                    const f32x4 v = ldg4(ba.base + (size_t)(16 * (g + t)));
+                    bt[4 * t] = v[0]; bt[4 * t + 1] = v[1]; bt[4 * t + 2] = v[2]; bt[4 * t + 3] = v[3];
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) bt[4 * t + s] = ldg(ba.base + (size_t)(16 * (g + t) + s) * ba.ldb);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            if (t < nt) {
+                const float4 a = *reinterpret_cast<const float4*>(arow + 16 * (g + t));
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bt[4 * t], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bt[4 * t + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bt[4 * t + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bt[4 * t + 3], acc, 0, 0, 0);
+            }
+        }
+    }
+    return acc;
+}
+
+template <int NA>  // NA = float4 loads per thread that cover the A tile: 16 * K / 4 <= NA * 256
+__device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
     const int local = blockIdx.x - T.tile0;
     const int tm = local / T.ntn, tn = local - tm * T.ntn;
     const int row0 = tm * 16;
@@ -169,18 +269,66 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_gemm16_kernel(const GemmTask*
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int flags = T.flags;
+    const int WK = T.wk, NW = 4 / WK;
+    float* red = lds + 16 * S;  // [WK-1][NW][64] float4 partial accumulators
+#ifdef FQL_STAMPS
+    unsigned long long stamp[8];
+    int nst = 0;
+#define STAMP() do { __builtin_amdgcn_s_waitcnt(0); stamp[nst++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    STAMP();
+#else
+#define STAMP() do {} while (0)
+#endif
 
-    // ---- stage A tile
+    // ---- issue every independent load of the tile up front: the A tile (<= 16 x 16 B per thread), the
+    // wave's first two B chunks and its bias.  At one wave per SIMD only explicit parallel issue hides
+    // the ~0.3-1.5 us (cold, cross-XCD) load latency; a rolled staging loop would serialise it.
+    const int nt = wave % NW, kp = wave / NW;
+    const int n0 = (tn * NW + nt) * 16;
+    const int c = lane & 15, q = lane >> 4;
+    const bool active = n0 < N;
+    const int G = K >> 4;
+    const int gbeg = (kp * G) / WK, gend = ((kp + 1) * G) / WK;
+    const bool transb = (flags & GF_TRANS_B) != 0;
+    const int k4 = K >> 2;
+    const int nA = 16 * k4;
+    float b0[32], b1[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { b0[i] = 0.f; b1[i] = 0.f; }  // defined on every path: keeps them in VGPRs
+    BAddr ba = transb ? gemm_baddr<true>(T, n0, c, q) : gemm_baddr<false>(T, n0, c, q);
+    float bias = 0.f;
+    if (active) {
+        const int nfull = (gend - gbeg) >> 3;
+        if (transb) {
+            if (nfull > 0) gemm_load_chunk<true>(b0, ba.base + (size_t)(16 * gbeg) * ba.kstep, ba.ldb);
+            if (nfull > 1) gemm_load_chunk<true>(b1, ba.base + (size_t)(16 * (gbeg + 8)) * ba.kstep, ba.ldb);
+        } else {
+            if (nfull > 0) gemm_load_chunk<false>(b0, ba.base + (size_t)(16 * gbeg) * ba.kstep, ba.ldb);
+            if (nfull > 1) gemm_load_chunk<false>(b1, ba.base + (size_t)(16 * (gbeg + 8)) * ba.kstep, ba.ldb);
+        }
+        if ((flags & GF_BIAS) && kp == 0) bias = ldg(T.bias + n0 + c);
+    }
     {
-        const int k4 = K >> 2;
+        f32x4 av[NA];
         const float* __restrict__ Ag = T.A + (size_t)row0 * T.lda;
-        for (int f = tid; f < 16 * k4; f += FQL_THREADS) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int f = min(tid + i * FQL_THREADS, nA - 1);  // clamped, unconditional
             const int r = f / k4, kk = f - r * k4;
-            const float4 v = *reinterpret_cast<const float4*>(Ag + (size_t)r * T.lda + 4 * kk);
-            *reinterpret_cast<float4*>(&lds[r * S + 4 * kk]) = v;
+            av[i] = ldg4(Ag + (size_t)r * T.lda + 4 * kk);
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int f = tid + i * FQL_THREADS;
+            if (f < nA) {
+                const int r = f / k4, kk = f - r * k4;
+                *reinterpret_cast<f32x4*>(&lds[r * S + 4 * kk]) = av[i];
+            }
         }
     }
+    STAMP();
     __syncthreads();
+    STAMP();
     if (flags & GF_A_LN) {
         // 16 threads per row; flax LayerNorm: eps 1e-6, var = max(0, E[x^2] - E[x]^2)
         const int r = tid >> 4, j = tid & 15;
@@ -202,9 +350,9 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_gemm16_kernel(const GemmTask*
         const bool wr = (flags & GF_LN_WRITE) && tn == 0;
         for (int k = j; k < K; k += 16) {
             float v = 0.f;
-            if (k < width) v = (lds[r * S + k] - mean) * rstd * T.ln_g[k] + T.ln_b[k];
+            if (k < width) v = (lds[r * S + k] - mean) * rstd * ldg(T.ln_g + k) + ldg(T.ln_b + k);
             lds[r * S + k] = v;
-            if (wr) T.ln_xout[(size_t)(row0 + r) * T.lda + k] = v;
+            if (wr) stg(T.ln_xout + (size_t)(row0 + r) * T.lda + k, v);
         }
         if (wr && j == 0) {
             T.ln_stats[2 * (row0 + r)] = mean;
@@ -213,40 +361,24 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_gemm16_kernel(const GemmTask*
         __syncthreads();
     }
 
-    const int n0 = tn * 64 + wave * 16;
-    if (n0 >= N) return;  // no barriers below
-    const int c = lane & 15, q = lane >> 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float* __restrict__ arow = &lds[c * S + 4 * q];  // A row = lane&15
-    if (flags & GF_TRANS_B) {
-        const float* __restrict__ brow = T.B + (size_t)(n0 + c) * T.ldb + 4 * q;
-#pragma unroll 4
-        for (int j = 0; j < K; j += 16) {
-            const float4 a = *reinterpret_cast<const float4*>(arow + j);
-            const float4 b = *reinterpret_cast<const float4*>(brow + j);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
-        }
-    } else {
-        const float* __restrict__ bcol = T.B + (size_t)(4 * q) * T.ldb + n0 + c;
-        const size_t ldb = T.ldb;
-#pragma unroll 4
-        for (int j = 0; j < K; j += 16) {
-            const float4 a = *reinterpret_cast<const float4*>(arow + j);
-            const float* bp = bcol + (size_t)j * ldb;
-            const float b0 = bp[0], b1 = bp[ldb], b2 = bp[2 * ldb], b3 = bp[3 * ldb];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b2, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b3, acc, 0, 0, 0);
-        }
+    if (active)
+        acc = transb ? gemm_wave<true>(ba, lds, S, gbeg, gend, c, q, b0, b1) : gemm_wave<false>(ba, lds, S, gbeg, gend, c, q, b0, b1);
+    STAMP();
+    if (WK > 1) {
+        if (kp > 0) *reinterpret_cast<f32x4*>(&red[(((kp - 1) * NW + nt) * 64 + lane) * 4]) = acc;
+        __syncthreads();
+        if (kp > 0) return;
+        for (int p = 1; p < WK; ++p) acc += *reinterpret_cast<const f32x4*>(&red[(((p - 1) * NW + nt) * 64 + lane) * 4]);
     }
+    if (!active) return;
+    STAMP();
+#ifdef FQL_STAMPS
+    const int FQL_STAMP_EPILOGUE = 1;
+#endif
 
     // ---- epilogue. C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
     const int n = n0 + c;
-    const float bias = (flags & GF_BIAS) ? T.bias[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = row0 + 4 * q + i;
@@ -256,64 +388,131 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_gemm16_kernel(const GemmTask*
             // agents/fql.py:166-169: actions = actions + vels / flow_steps ; t = (i+1)/flow_steps
             float* xr = T.aux + (size_t)row * T.i0 + T.i1;
             if (n < T.i2) {
-                const float a = xr[n] + v * T.f0;
-                xr[n] = a;
-                if (flags & GF_EULER_LAST) T.aux2[(size_t)row * T.ldc + n] = clip1(a);
+                const float a = ldg(xr + n) + v * T.f0;
+                stg(xr + n, a);
+                if (flags & GF_EULER_LAST) stg(T.aux2 + (size_t)row * T.ldc + n, clip1(a));
             }
-            if (n == 0) xr[T.i2] = T.f1;
+            if (n == 0) stg(xr + T.i2, T.f1);
             continue;
         }
-        if (flags & GF_SAVE_Z) T.Zout[o] = v;
+        if (flags & GF_SAVE_Z) stg(T.Zout + o, v);
         if (flags & GF_GELU) v = gelu_f(v);
-        if (flags & GF_GELUGRAD) v *= gelu_grad_f(T.Zprev[o]);
+        if (flags & GF_GELUGRAD) v *= gelu_grad_f(ldg(T.Zprev + o));
         if (flags & GF_CLIP_OUT) v = clip1(v);
-        T.C[o] = v;
+        stg(T.C + o, v);
     }
+#ifdef FQL_STAMPS
+    STAMP();
+    if (lane == 0 && wave == 0 && T.aux) {
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(T.aux) + (size_t)blockIdx.x * 8;
+        for (int i = 0; i < nst; ++i) d[i] = stamp[i];
+    }
+#endif
+}
+
+__global__ __launch_bounds__(FQL_THREADS) void fql_gemm16_kernel(const GemmTask* __restrict__ tasks, int ntasks) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int ti = find_task(tasks, ntasks, blockIdx.x);
+    const GemmTask& T = tasks[ti];
+    if (T.K <= 128) gemm16_body<2>(T, lds);
+    else if (T.K <= 512) gemm16_body<8>(T, lds);
+    else gemm16_body<16>(T, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
 // K9 wgrad: dW[Kin, N] = X^T dZ (contraction over the batch), db[n] = sum_m dZ[m, n]
-//   implied by jax.grad, utils/flax_utils.py:137.  Workgroup tile 16 (Kin) x 64 (N), wave = 16x16.
+//   implied by jax.grad, utils/flax_utils.py:137.
+// Workgroup tile 16 (Kin) x 64 (N).  The 4 waves split the batch (contraction) dimension, each holds
+// four 16x16 accumulators that share one X^T fragment per MFMA step (5 dword loads per 4 MFMAs),
+// loads are issued a chunk of 8 steps (40 VGPRs) ahead; partial tiles meet in LDS and wave t
+// finalises column tile t.  Summation order is fixed, so gradients are bitwise reproducible.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wgrad_load_chunk(float (&a)[8], float (&b)[32], const float* xp, const float* zp,
+                                                 size_t sx, size_t sz, int cnt, int ntv) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bool v = i < cnt;
+        a[i] = v ? ldg(xp + i * sx) : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[4 * i + t] = (v && t < ntv) ? ldg(zp + i * sz + 16 * t) : 0.f;
+    }
+}
 __global__ __launch_bounds__(FQL_THREADS) void fql_wgrad_kernel(const WgradTask* __restrict__ tasks, int ntasks) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 * 4];  // [wave][tile][lane] float4
+    __shared__ float redb[4][64];
     const int ti = find_task(tasks, ntasks, blockIdx.x);
     const WgradTask& T = tasks[ti];
     const int local = blockIdx.x - T.tile0;
     const int tk = local / T.ntn, tn = local - tk * T.ntn;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n0 = tn * 64 + wave * 16;
-    if (n0 >= T.N) return;
     const int c = lane & 15, q = lane >> 4;
-    const int k0 = tk * 16;
-    const float* __restrict__ xp = T.X + (size_t)q * T.ldx + k0 + c;   // A[i = kin][k = m]
-    const float* __restrict__ zp = T.dZ + (size_t)q * T.ldz + n0 + c;  // B[k = m][j = n]
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    float bs = 0.f;
+    const int k0 = tk * 16, n0 = tn * 64;
+    const int ntv = min(4, (T.N - n0) >> 4);  // valid 16-column tiles in this workgroup
+    const int steps = T.M >> 4;               // MFMA steps (4 batch rows each) per wave
     const size_t sx = (size_t)4 * T.ldx, sz = (size_t)4 * T.ldz;
-#pragma unroll 8
-    for (int m = 0; m < T.M; m += 4) {
-        const float a = *xp, b = *zp;
-        xp += sx; zp += sz;
-        bs += b;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    const float* __restrict__ xp = T.X + (size_t)(4 * wave * steps + q) * T.ldx + k0 + c;   // A[i = kin][k = m]
+    const float* __restrict__ zp = T.dZ + (size_t)(4 * wave * steps + q) * T.ldz + n0 + c;  // B[k = m][j = n]
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    float a0[8], b0[32], a1[8], b1[32];
+    auto mma = [&](const float(&a)[8], const float(&b)[32]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                bs[t] += b[4 * i + t];
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[4 * i + t], acc[t], 0, 0, 0);
+            }
+    };
+    wgrad_load_chunk(a0, b0, xp, zp, sx, sz, steps, ntv);
+    for (int s = 0; s < steps; s += 16) {
+        if (s + 8 < steps) wgrad_load_chunk(a1, b1, xp + (s + 8) * sx, zp + (s + 8) * sz, sx, sz, steps - s - 8, ntv);
+        mma(a0, b0);
+        if (s + 8 < steps) {
+            if (s + 16 < steps) wgrad_load_chunk(a0, b0, xp + (s + 16) * sx, zp + (s + 16) * sz, sx, sz, steps - s - 16, ntv);
+            mma(a1, b1);
+        }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) T.dW[(size_t)(k0 + 4 * q + i) * T.ldw + n0 + c] = acc[i];
-    if (tk == 0 && T.db) {
-        bs += __shfl_xor(bs, 16);
-        bs += __shfl_xor(bs, 32);
-        if (q == 0) T.db[n0 + c] = bs;
+    for (int t = 0; t < 4; ++t) {
+        *reinterpret_cast<f32x4*>(&red[((wave * 4 + t) * 64 + lane) * 4]) = acc[t];
+        float v = bs[t];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (q == 0) redb[wave][16 * t + c] = v;
+    }
+    __syncthreads();
+    if (wave < ntv) {
+        f32x4 r = *reinterpret_cast<const f32x4*>(&red[((0 * 4 + wave) * 64 + lane) * 4]);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) r += *reinterpret_cast<const f32x4*>(&red[((w * 4 + wave) * 64 + lane) * 4]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stg(T.dW + (size_t)(k0 + 4 * q + i) * T.ldw + n0 + 16 * wave + c, r[i]);
+        if (tk == 0 && T.db && q == 0) {
+            const int j = 16 * wave + c;
+            T.db[n0 + j] = redb[0][j] + redb[1][j] + redb[2][j] + redb[3][j];
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm backward fused with GELU' (critic, utils/networks.py:56-58 reversed):
 //   dxhat = dY*gamma ; dg = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)) ; dZ = dg GELU'(z)
-// row tiles: one wave per row.  Column tiles (param grads): dgamma = sum_m dY xhat, dbeta = sum_m dY,
-// one workgroup per 64 columns, fixed summation order (deterministic).
+// row tiles: one wave per row, the row lives in registers (one tanh per element).  Column tiles
+// (param grads): dgamma = sum_m dY xhat, dbeta = sum_m dY; one workgroup per 16 columns, 16 row
+// groups per workgroup, fixed summation order (deterministic).
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gelu_both(float x, float& g, float& dg) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    const float th = tanhf(u);
+    const float du = 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
+    g = 0.5f * x * (1.0f + th);
+    dg = 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * du;
+}
 __global__ __launch_bounds__(FQL_THREADS) void fql_lnbwd_kernel(const LnBwdTask* __restrict__ tasks, int ntasks) {
-    __shared__ float red[2][4][64];
+    __shared__ float red[2][16][16];
     const int ti = find_task(tasks, ntasks, blockIdx.x);
     const LnBwdTask& T = tasks[ti];
     const int local = blockIdx.x - T.tile0;
@@ -324,11 +523,19 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_lnbwd_kernel(const LnBwdTask*
         const float mean = T.stats[2 * row], rstd = T.stats[2 * row + 1];
         const float* dy = T.dY + (size_t)row * T.ld;
         const float* z = T.Z + (size_t)row * T.ld;
+        float d[16], xh[16], dg[16];  // H <= 1024: <= 16 elements per lane, k = lane + 64 i
         float s1 = 0.f, s2 = 0.f;
-        for (int k = lane; k < T.width; k += 64) {
-            const float xh = (gelu_f(z[k]) - mean) * rstd;
-            const float d = dy[k] * T.gamma[k];
-            s1 += d; s2 += d * xh;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int k = lane + 64 * i;
+            d[i] = 0.f; xh[i] = 0.f; dg[i] = 0.f;
+            if (k < T.width) {
+                float g;
+                gelu_both(z[k], g, dg[i]);
+                xh[i] = (g - mean) * rstd;
+                d[i] = dy[k] * T.gamma[k];
+                s1 += d[i]; s2 += d[i] * xh[i];
+            }
         }
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -338,32 +545,30 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_lnbwd_kernel(const LnBwdTask*
         const float inv = 1.0f / (float)T.width;
         const float m1 = s1 * inv, m2 = s2 * inv;
         float* dz = T.dZ + (size_t)row * T.ld;
-        for (int k = lane; k < T.H; k += 64) {
-            float v = 0.f;
-            if (k < T.width) {
-                const float zz = z[k];
-                const float xh = (gelu_f(zz) - mean) * rstd;
-                const float d = dy[k] * T.gamma[k];
-                v = rstd * (d - m1 - xh * m2) * gelu_grad_f(zz);
-            }
-            dz[k] = v;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int k = lane + 64 * i;
+            if (k < T.H) dz[k] = (k < T.width) ? rstd * (d[i] - m1 - xh[i] * m2) * dg[i] : 0.f;
         }
     } else {
-        const int col = (local - T.ntiles_rows) * 64 + lane;
+        const int cc = threadIdx.x & 15, rg = threadIdx.x >> 4;
+        const int col = (local - T.ntiles_rows) * 16 + cc;
         float sg = 0.f, sb = 0.f;
         if (col < T.width) {
-            for (int m = wave; m < T.M; m += 4) {
+#pragma unroll 4
+            for (int m = rg; m < T.M; m += 16) {
                 const float mean = T.stats[2 * m], rstd = T.stats[2 * m + 1];
-                const float d = T.dY[(size_t)m * T.ld + col];
+                const float dd = T.dY[(size_t)m * T.ld + col];
                 const float xh = (gelu_f(T.Z[(size_t)m * T.ld + col]) - mean) * rstd;
-                sg += d * xh; sb += d;
+                sg += dd * xh; sb += dd;
             }
         }
-        red[0][wave][lane] = sg; red[1][wave][lane] = sb;
+        red[0][rg][cc] = sg; red[1][rg][cc] = sb;
         __syncthreads();
-        if (wave == 0 && col < T.H) {
-            const float g = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
-            const float b = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+        if (rg == 0 && col < T.H) {
+            float g = 0.f, b = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { g += red[0][r][cc]; b += red[1][r][cc]; }
             T.dgamma[col] = (col < T.width) ? g : 0.f;
             T.dbeta[col] = (col < T.width) ? b : 0.f;
         }
@@ -383,7 +588,7 @@ struct DevState {
     float info[16];      // the 13 info scalars (+ scratch)
     float gmax_bits_pad; // unused
     int gmax, gmin;      // ordered-int encodings for atomicMax/Min
-    float leaf_sumsq[64];
+    float leaf_sumsq[128];
 };
 
 struct SrcDesc {  // where the batch comes from; rewritten by the host only when it changes
@@ -663,21 +868,41 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_begin_step_kernel(DevState* s
 
 __global__ __launch_bounds__(FQL_THREADS) void fql_adam_kernel(AdamArgs A) {
     __shared__ float sh[4];
-    const AdamChunk ch = A.chunks[blockIdx.x];
+    const AdamChunk ch = A.chunks[blockIdx.x];  // <= 4096 elements, offset and length multiples of 4
     const float c1 = (float)(1.0 - A.st->b1pow), c2 = (float)(1.0 - A.st->b2pow);
     const float gsc = A.st->grad_scale;
     float ss = 0.f, mx = -INFINITY, mn = INFINITY;
-    for (int i = threadIdx.x; i < ch.len; i += FQL_THREADS) {
-        const int o = ch.off + i;
-        const float g = A.G[o] * gsc;
-        const float p = A.P[o];
-        const float m = 0.9f * A.Mu[o] + 0.1f * g;
-        const float v = 0.999f * A.Nu[o] + 0.001f * g * g;
-        A.Mu[o] = m; A.Nu[o] = v;
-        const float mh = m / c1, vh = v / c2;
-        A.P[o] = p - A.lr * (mh / (sqrtf(vh) + 1e-8f));
-        if (o < A.critic_size) A.T[o] = p * A.tau + A.T[o] * (1.0f - A.tau);
-        ss += g * g; mx = fmaxf(mx, g); mn = fminf(mn, g);
+    const int n4 = ch.len >> 2;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = threadIdx.x + it * FQL_THREADS;
+        if (i < n4) {
+            const int o = ch.off + 4 * i;
+            float4 g = *reinterpret_cast<const float4*>(A.G + o);
+            const float4 p = *reinterpret_cast<const float4*>(A.P + o);
+            float4 m = *reinterpret_cast<const float4*>(A.Mu + o);
+            float4 v = *reinterpret_cast<const float4*>(A.Nu + o);
+            float4 pn;
+            float* gp = &g.x; const float* pp = &p.x; float* mp = &m.x; float* vp = &v.x; float* pnp = &pn.x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ge = gp[e] * gsc;
+                mp[e] = 0.9f * mp[e] + 0.1f * ge;
+                vp[e] = 0.999f * vp[e] + 0.001f * ge * ge;
+                const float mh = mp[e] / c1, vh = vp[e] / c2;
+                pnp[e] = pp[e] - A.lr * (mh / (sqrtf(vh) + 1e-8f));
+                ss += ge * ge; mx = fmaxf(mx, ge); mn = fminf(mn, ge);
+            }
+            *reinterpret_cast<float4*>(A.Mu + o) = m;
+            *reinterpret_cast<float4*>(A.Nu + o) = v;
+            *reinterpret_cast<float4*>(A.P + o) = pn;
+            if (o < A.critic_size) {
+                float4 t = *reinterpret_cast<const float4*>(A.T + o);
+                t.x = p.x * A.tau + t.x * (1.0f - A.tau); t.y = p.y * A.tau + t.y * (1.0f - A.tau);
+                t.z = p.z * A.tau + t.z * (1.0f - A.tau); t.w = p.w * A.tau + t.w * (1.0f - A.tau);
+                *reinterpret_cast<float4*>(A.T + o) = t;
+            }
+        }
     }
     const float tss = block_sum(ss, sh);
     const float tmx = block_max(mx, sh), tmn = -block_max(-mn, sh);
