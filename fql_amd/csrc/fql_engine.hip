@@ -106,6 +106,8 @@ struct Op {
     LossActorArgs la;
     int fin_mode = 0;
     int level = 0;
+    int lane = 0;            // 0 = critical lane (Euler chain, one-step backward), 1 = side lane
+    std::vector<int> deps;   // indices of earlier ops this op must follow (RAW / WAW / WAR)
 };
 
 struct Launch {
@@ -114,11 +116,18 @@ struct Launch {
     size_t lds = 0;
     void* table = nullptr;  // device task table (GEMM/WGRAD/LNBWD)
     Op op;                  // arg-struct kernels
+    int lane = 0;
+    bool tmt2 = false, kbig = false;
+    std::vector<int> waits;      // launches of the OTHER lane that must have completed
+    bool record_after = false;   // some launch of the other lane waits on this one
+    hipEvent_t ev = nullptr;
 };
 
 struct Program {
     std::vector<Op> ops;
     std::vector<Launch> launches;
+    bool two_lanes = false;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     int64_t macs = 0;
@@ -141,7 +150,8 @@ struct fql_engine {
     fql_config cfg{};
     uint64_t seed = 0;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    int emit_lane = 0;
     std::string err;
 
     Net nets[NUM_NETS];
@@ -374,6 +384,11 @@ struct fql_engine {
         return p;
     }
 
+    void push(Program& pr, Op& op) {
+        op.lane = emit_lane;
+        pr.ops.push_back(op);
+    }
+
     // forward of one pass appended to a program.  final_flags: epilogue of the last layer.
     void emit_forward(Program& pr, const PassBuf& p, bool save, int final_flags = 0, float* aux = nullptr,
                       float* aux2 = nullptr, float f0 = 0.f, float f1 = 0.f) {
@@ -423,7 +438,7 @@ struct fql_engine {
                     op.writes.push_back(t.C);
                 }
             }
-            pr.ops.push_back(op);
+            push(pr, op);
         }
     }
 
@@ -449,7 +464,7 @@ struct fql_engine {
                 w.M = M; w.Kin = ly.in_p; w.N = ly.out_p;
                 op.reads = {xin_id, dz};
                 op.writes = {w.dW, w.db};
-                pr.ops.push_back(op);
+                push(pr, op);
             }
             if (l == 0 && !input_grad) break;
             // dgrad: dX = dZ W^T
@@ -465,14 +480,14 @@ struct fql_engine {
             if (l == 0) {
                 t.C = p.dx0;
                 op.writes = {t.C};
-                pr.ops.push_back(op);
+                push(pr, op);
                 break;
             }
             const Layer& prev = n.layers[l - 1];
             if (prev.ln) {
                 t.C = p.dy[l - 1];
                 op.writes = {t.C};
-                pr.ops.push_back(op);
+                push(pr, op);
                 Op lo{};
                 lo.type = OP_LNBWD;
                 LnBwdTask& q = lo.ln;
@@ -487,14 +502,14 @@ struct fql_engine {
                 lo.reads = {q.dY, p.z[l - 1], p.stats[l - 1], q.gamma};
                 lo.writes = {q.dZ};
                 if (param_grads) { lo.writes.push_back(q.dgamma); lo.writes.push_back(q.dbeta); }
-                pr.ops.push_back(lo);
+                push(pr, lo);
             } else {
                 t.C = p.dz[l - 1];
                 t.flags |= GF_GELUGRAD;
                 t.Zprev = rows(p.z[l - 1], prev.out_p);
                 op.reads.push_back(p.z[l - 1]);
                 op.writes = {t.C};
-                pr.ops.push_back(op);
+                push(pr, op);
             }
         }
     }
@@ -505,61 +520,77 @@ struct fql_engine {
     static bool is_table(OpType t) { return t == OP_GEMM || t == OP_WGRAD || t == OP_LNBWD; }
 
     void schedule(Program& pr, std::vector<void*>& owner) {
-        std::map<const void*, int> last_write;               // buffer -> level of last writer
-        std::map<const void*, int> last_read;                // buffer -> max level of readers since last write
-        for (Op& op : pr.ops) {
+        // list scheduling: level = 1 + max level of every op this one conflicts with (RAW, WAW, WAR)
+        std::map<const void*, int> last_writer;               // buffer -> op index of last writer
+        std::map<const void*, std::vector<int>> readers;      // buffer -> ops reading it since that write
+        for (int oi = 0; oi < (int)pr.ops.size(); ++oi) {
+            Op& op = pr.ops[oi];
+            op.deps.clear();
+            for (const void* r : op.reads) {
+                auto it = last_writer.find(r);
+                if (it != last_writer.end()) op.deps.push_back(it->second);
+            }
+            for (const void* w : op.writes) {
+                auto it = last_writer.find(w);
+                if (it != last_writer.end()) op.deps.push_back(it->second);
+                auto ir = readers.find(w);
+                if (ir != readers.end()) for (int r : ir->second) if (r != oi) op.deps.push_back(r);
+            }
             int lv = 0;
-            for (const void* r : op.reads) {
-                auto it = last_write.find(r);
-                if (it != last_write.end()) lv = std::max(lv, it->second + 1);
-            }
-            for (const void* w : op.writes) {
-                auto it = last_write.find(w);
-                if (it != last_write.end()) lv = std::max(lv, it->second + 1);
-                auto ir = last_read.find(w);
-                if (ir != last_read.end()) lv = std::max(lv, ir->second + 1);
-            }
+            for (int d : op.deps) lv = std::max(lv, pr.ops[d].level + 1);
             op.level = lv;
-            for (const void* r : op.reads) {
-                auto& x = last_read[r];
-                x = std::max(x, lv);
-            }
+            for (const void* r : op.reads) readers[r].push_back(oi);
             for (const void* w : op.writes) {
-                last_write[w] = lv;
-                last_read.erase(w);
+                last_writer[w] = oi;
+                readers.erase(w);
             }
         }
         int maxlv = 0;
         for (const Op& op : pr.ops) maxlv = std::max(maxlv, op.level);
         pr.launches.clear();
+        pr.two_lanes = false;
+        std::vector<int> launch_of(pr.ops.size(), -1);
         for (int lv = 0; lv <= maxlv; ++lv) {
+          for (int lane = 0; lane < 2; ++lane) {
             for (int ty = 0; ty <= OP_FINALIZE; ++ty) {
                 std::vector<const Op*> sel;
-                for (const Op& op : pr.ops)
-                    if (op.level == lv && op.type == ty) sel.push_back(&op);
+                for (int oi = 0; oi < (int)pr.ops.size(); ++oi) {
+                    const Op& op = pr.ops[oi];
+                    if (op.level == lv && op.type == ty && op.lane == lane) sel.push_back(&op);
+                }
                 if (sel.empty()) continue;
+                if (lane == 1) pr.two_lanes = true;
                 if (!is_table((OpType)ty)) {
                     for (const Op* o : sel) {
                         Launch L;
                         L.type = (OpType)ty;
                         L.op = *o;
+                        L.lane = lane;
+                        launch_of[o - pr.ops.data()] = (int)pr.launches.size();
                         pr.launches.push_back(L);
                     }
                     continue;
                 }
                 Launch L;
                 L.type = (OpType)ty;
+                L.lane = lane;
+                for (const Op* o : sel) launch_of[o - pr.ops.data()] = (int)pr.launches.size();
                 L.ntasks = (int)sel.size();
                 int tile = 0;
                 if (ty == OP_GEMM) {
                     std::vector<GemmTask> tb;
                     for (const Op* o : sel) {
                         GemmTask t = o->gemm;
+                        static const int tmt_side = getenv("FQL_TMT") ? atoi(getenv("FQL_TMT")) : 2;
                         t.wk = (t.N <= 16) ? 4 : 2;
+                        // throughput lane: two 16-row tiles per workgroup share each B fragment
+                        t.tmt = (lane == 1 && tmt_side == 2 && t.M % 32 == 0 && t.M >= 256 && t.N >= 32) ? 2 : 1;
                         t.ntn = (t.N / 16 + (4 / t.wk) - 1) / (4 / t.wk);
                         t.tile0 = tile;
-                        tile += (t.M / 16) * t.ntn;
-                        L.lds = std::max(L.lds, ((size_t)16 * (t.K + 4) + 1024) * sizeof(float));
+                        tile += (t.M / (16 * t.tmt)) * t.ntn;
+                        if (t.tmt == 2) L.tmt2 = true;
+                        if (t.K > 512) L.kbig = true;
+                        L.lds = std::max(L.lds, ((size_t)16 * t.tmt * (t.K + 4) + 1024 * t.tmt) * sizeof(float));
                         tb.push_back(t);
                     }
                     L.table = dalloc(owner, tb.size() * sizeof(GemmTask) / sizeof(float) + 4);
@@ -590,14 +621,49 @@ struct fql_engine {
                 L.grid = tile;
                 pr.launches.push_back(L);
             }
+          }
+        }
+        // cross-lane edges: a launch waits for the latest launch of the other lane it depends on (lane streams
+        // are in-order, so that covers the earlier ones); skip waits already implied by an earlier wait.
+        int waited_upto[2] = {-1, -1};  // per waiting lane: highest other-lane launch index already waited for
+        for (int li = 0; li < (int)pr.launches.size(); ++li) {
+            Launch& L = pr.launches[li];
+            int need = -1;
+            for (int oi = 0; oi < (int)pr.ops.size(); ++oi) {
+                if (launch_of[oi] != li) continue;
+                for (int d : pr.ops[oi].deps) {
+                    const int dl = launch_of[d];
+                    if (pr.launches[dl].lane != L.lane) need = std::max(need, dl);
+                }
+            }
+            if (need > waited_upto[L.lane]) {
+                L.waits.push_back(need);
+                pr.launches[need].record_after = true;
+                waited_upto[L.lane] = need;
+            }
         }
     }
 
-    void run_launches(const Program& pr, hipStream_t s) {
-        for (const Launch& L : pr.launches) {
+    // s2 != nullptr: two-stream issue (graph capture of a two-lane program); otherwise everything goes to `s0` in
+    // emission order, which is a topological order of the program.
+    void run_launches(Program& pr, hipStream_t s0, hipStream_t s2 = nullptr) {
+        const bool par = s2 != nullptr && pr.two_lanes;
+        if (par) {
+            if (!pr.ev_fork) HIP_CHECK(hipEventCreateWithFlags(&pr.ev_fork, hipEventDisableTiming));
+            if (!pr.ev_join) HIP_CHECK(hipEventCreateWithFlags(&pr.ev_join, hipEventDisableTiming));
+            HIP_CHECK(hipEventRecord(pr.ev_fork, s0));
+            HIP_CHECK(hipStreamWaitEvent(s2, pr.ev_fork, 0));
+        }
+        for (Launch& L : pr.launches) {
+            hipStream_t s = (par && L.lane == 1) ? s2 : s0;
+            if (par)
+                for (int w : L.waits) HIP_CHECK(hipStreamWaitEvent(s, pr.launches[w].ev, 0));
             switch (L.type) {
                 case OP_GEMM:
-                    hipLaunchKernelGGL(fql_gemm16_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
+                    if (L.tmt2 && L.kbig) hipLaunchKernelGGL((fql_gemm16_kernel<true, true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
+                    else if (L.tmt2) hipLaunchKernelGGL((fql_gemm16_kernel<true, false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
+                    else if (L.kbig) hipLaunchKernelGGL((fql_gemm16_kernel<false, true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
+                    else hipLaunchKernelGGL((fql_gemm16_kernel<false, false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
                     break;
                 case OP_WGRAD:
                     hipLaunchKernelGGL(fql_wgrad_kernel, dim3(L.grid), dim3(FQL_THREADS), 0, s, (const WgradTask*)L.table, L.ntasks);
@@ -635,6 +701,14 @@ struct fql_engine {
                     hipLaunchKernelGGL(fql_finalize_kernel, dim3(1), dim3(64), 0, s, d_state, n_train_leaves, L.op.fin_mode);
                     break;
             }
+            if (par && L.record_after) {
+                if (!L.ev) HIP_CHECK(hipEventCreateWithFlags(&L.ev, hipEventDisableTiming));
+                HIP_CHECK(hipEventRecord(L.ev, s));
+            }
+        }
+        if (par) {
+            HIP_CHECK(hipEventRecord(pr.ev_join, s2));
+            HIP_CHECK(hipStreamWaitEvent(s0, pr.ev_join, 0));
         }
         HIP_CHECK(hipGetLastError());
     }
@@ -645,7 +719,7 @@ struct fql_engine {
         HIP_CHECK(hipStreamSynchronize(stream));
         HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
         try {
-            run_launches(pr, stream);
+            run_launches(pr, stream, stream2);
         } catch (...) {
             hipGraph_t g = nullptr;
             hipStreamEndCapture(stream, &g);
@@ -659,6 +733,9 @@ struct fql_engine {
     void free_program(Program& pr) {
         if (pr.exec) hipGraphExecDestroy(pr.exec);
         if (pr.graph) hipGraphDestroy(pr.graph);
+        for (Launch& L : pr.launches) if (L.ev) hipEventDestroy(L.ev);
+        if (pr.ev_fork) hipEventDestroy(pr.ev_fork);
+        if (pr.ev_join) hipEventDestroy(pr.ev_join);
         pr = Program{};
     }
 
@@ -671,13 +748,17 @@ struct fql_engine {
         const int ap = pad16(ad);
         DevState* st = d_state;
         const void* INFO = &st->info[0];
+        // Lane 0 carries the critical path (prep -> Euler chain -> actor loss -> one-step backward); the rest of
+        // the step runs beside it on lane 1 (a second graph branch) and only meets it at the actor loss.
+        emit_lane = 0;
         {   // batch gather + noise + every network input
             Op op{};
             op.type = OP_PREP;
             op.prep = PrepArgs{d_src, st, seed, B, od, ad, inp_c, inp_b, ap, X_os, X_bc, X_eu, X_c1, X_c2, X_ct, vel, w_rew, w_mask, w_act};
             op.writes = {X_os, X_bc, X_eu, X_c1, X_c2, X_ct, vel, w_rew, w_mask, w_act};
-            pr.ops.push_back(op);
+            push(pr, op);
         }
+        emit_lane = 1;
         // one-step actor on [next_obs|eps1 ; obs|z ; obs|eps2]  (agents/fql.py:25,65,82)
         emit_forward(pr, p_os, with_grads);
         {
@@ -686,7 +767,7 @@ struct fql_engine {
             op.postos = PostOsArgs{p_os.out, w_act, X_ct, X_c2, st, B, od, ad, inp_c, ap};
             op.reads = {p_os.out, w_act};
             op.writes = {X_ct, X_c2, INFO};
-            pr.ops.push_back(op);
+            push(pr, op);
         }
         // critic(obs, actions) with grad params; target critic(next_obs, next_actions)  (fql.py:28,36)
         for (int e = 0; e < 2; ++e) emit_forward(pr, p_c1[e], with_grads);
@@ -700,7 +781,7 @@ struct fql_engine {
             op.reads = {p_c1[0].out, p_c1[1].out, p_ct[0].out, p_ct[1].out, w_rew, w_mask};
             op.writes = {INFO};
             if (with_grads) { op.writes.push_back(p_c1[0].dz.back()); op.writes.push_back(p_c1[1].dz.back()); }
-            pr.ops.push_back(op);
+            push(pr, op);
         }
         if (with_grads)
             for (int e = 0; e < 2; ++e) emit_backward(pr, p_c1[e], 0, B, true, false);
@@ -713,7 +794,7 @@ struct fql_engine {
             op.reads = {p_bc.out, vel};
             op.writes = {INFO};
             if (with_grads) op.writes.push_back(p_bc.dz.back());
-            pr.ops.push_back(op);
+            push(pr, op);
         }
         if (with_grads) emit_backward(pr, p_bc, 0, B, true, false);
         // Q term: critic(obs, clip(actor_actions)) with stored params, input-differentiable (fql.py:69-76)
@@ -726,11 +807,12 @@ struct fql_engine {
             op.reads = {p_c2[0].out, p_c2[1].out};
             op.writes = {INFO};
             if (with_grads) { op.writes.push_back(p_c2[0].dz.back()); op.writes.push_back(p_c2[1].dz.back()); }
-            pr.ops.push_back(op);
+            push(pr, op);
         }
         if (with_grads)
             for (int e = 0; e < 2; ++e) emit_backward(pr, p_c2[e], 0, B, false, true);
         // Euler chain through the BC flow (fql.py:155-171): flow_steps sequential forwards
+        emit_lane = 0;
         const int fs = cfg.flow_steps;
         for (int s = 0; s < fs; ++s)
             emit_forward(pr, p_eu, false, GF_EULER | (s == fs - 1 ? GF_EULER_LAST : 0), X_eu, tgt, 1.0f / (float)fs,
@@ -747,7 +829,7 @@ struct fql_engine {
                 op.reads.push_back(p_c2[0].dx0); op.reads.push_back(p_c2[1].dx0);
                 op.writes.push_back(p_os_bwd.dz.back());
             }
-            pr.ops.push_back(op);
+            push(pr, op);
         }
         if (with_grads) emit_backward(pr, p_os_bwd, B, B, true, false);
         if (!with_grads) {
@@ -756,28 +838,29 @@ struct fql_engine {
             op.fin_mode = 0;
             op.reads = {INFO};
             op.writes = {INFO};
-            pr.ops.push_back(op);
+            push(pr, op);
         }
     }
 
     void build_opt_program(Program& pr) {
+        emit_lane = 0;
         DevState* st = d_state;
         const void* INFO = &st->info[0];
         Op b{};
         b.type = OP_BEGIN;
         b.writes = {st};
-        pr.ops.push_back(b);
+        push(pr, b);
         Op a{};
         a.type = OP_ADAM;
         a.reads = {st, G};
         a.writes = {P, Mu, Nu, INFO};
-        pr.ops.push_back(a);
+        push(pr, a);
         Op f{};
         f.type = OP_FINALIZE;
         f.fin_mode = 1;
         f.reads = {INFO};
         f.writes = {INFO, st};
-        pr.ops.push_back(f);
+        push(pr, f);
     }
 
     int64_t macs_per_update() const {
@@ -943,6 +1026,7 @@ struct fql_engine {
         ev->st_out = dalloc(W, (size_t)n_pad * ad);
         ev->p_os = make_pass(W, NET_OS, n_pad, ev->X, false, false);
         ev->p_eu = make_pass(W, NET_BC, n_pad, ev->Xf, false, false);
+        emit_lane = 0;
         emit_forward(ev->prog_os, ev->p_os, false, GF_CLIP_OUT);
         const int fs = cfg.flow_steps;
         for (int s = 0; s < fs; ++s)
@@ -1050,6 +1134,7 @@ int fql_create(const fql_config* cfg, uint64_t seed, fql_handle* out) {
             return FQL_E_NODEVICE;
         }
         HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
         h->build_nets();
         HIP_CHECK(hipMalloc((void**)&h->P, h->n_total * sizeof(float)));
         HIP_CHECK(hipMalloc((void**)&h->G, h->n_train * sizeof(float)));
@@ -1091,6 +1176,7 @@ int fql_destroy(fql_handle h) {
     if (h->h_src_ring) hipHostFree(h->h_src_ring);
     hipFree(h->ds_obs); hipFree(h->ds_act); hipFree(h->ds_rew); hipFree(h->ds_mask); hipFree(h->ds_nobs); hipFree(h->ds_row);
     if (h->stream) hipStreamDestroy(h->stream);
+    if (h->stream2) hipStreamDestroy(h->stream2);
     delete h;
     return FQL_OK;
 }

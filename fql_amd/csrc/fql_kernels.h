@@ -59,6 +59,7 @@ struct GemmTask {
     int tile0;          // first workgroup index of this task inside the launch
     int ntn;            // workgroup tiles along N
     int wk;             // K-split ways among the 4 waves (1, 2 or 4); column tiles per workgroup = 4 / wk
+    int tmt;            // 16-row tiles per workgroup (1 or 2)
     int i0, i1, i2;     // GF_EULER: ld of aux, column offset of the action block, act_dim
     float f0, f1;       // GF_EULER: 1/flow_steps, t_next
 };
@@ -211,19 +212,21 @@ __device__ __forceinline__ BAddr gemm_baddr(const GemmTask& T, int n0, int c, in
     a.kstep = TRANS ? 1 : a.ldb;
     return a;
 }
-// b0 / b1 already hold chunks 0 / 1 of [gbeg, gend) when they exist (issued before the A tile landed)
-template <bool TRANS>
-__device__ __forceinline__ f32x4 gemm_wave(const BAddr& ba, const float* lds_a, int S, int gbeg, int gend, int c, int q,
-                                           float (&b0)[32], float (&b1)[32]) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+// b0 / b1 already hold chunks 0 / 1 of [gbeg, gend) when they exist (issued before the A tile landed).
+// TMT row tiles (16 rows each) share every B fragment: TMT x the MFMA work per loaded B byte.
+template <bool TRANS, int TMT>
+__device__ __forceinline__ void gemm_wave(f32x4 (&acc)[TMT], const BAddr& ba, const float* lds_a, int S, int gbeg, int gend,
+                                          int c, int q, float (&b0)[32], float (&b1)[32]) {
     const float* __restrict__ arow = lds_a + c * S + 4 * q;
     int g = gbeg;
     const int nfull = (gend - gbeg) >> 3;
     for (int i = 0; i < nfull; i += 2) {
-        gemm_mma_chunk(acc, b0, arow + 16 * g);
+#pragma unroll
+        for (int r = 0; r < TMT; ++r) gemm_mma_chunk(acc[r], b0, arow + r * 16 * S + 16 * g);
         if (i + 2 < nfull) gemm_load_chunk<TRANS>(b0, ba.base + (size_t)(16 * (g + 16)) * ba.kstep, ba.ldb);
         if (i + 1 < nfull) {
-            gemm_mma_chunk(acc, b1, arow + 16 * (g + 8));
+#pragma unroll
+            for (int r = 0; r < TMT; ++r) gemm_mma_chunk(acc[r], b1, arow + r * 16 * S + 16 * (g + 8));
             if (i + 3 < nfull) gemm_load_chunk<TRANS>(b1, ba.base + (size_t)(16 * (g + 24)) * ba.kstep, ba.ldb);
         }
         g += 16;
@@ -248,29 +251,33 @@ __device__ __forceinline__ f32x4 gemm_wave(const BAddr& ba, const float* lds_a, 
 #pragma unroll
         for (int t = 0; t < 7; ++t) {
             if (t < nt) {
-                const float4 a = *reinterpret_cast<const float4*>(arow + 16 * (g + t));
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bt[4 * t], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bt[4 * t + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bt[4 * t + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bt[4 * t + 3], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < TMT; ++r) {
+                    const float4 a = *reinterpret_cast<const float4*>(arow + r * 16 * S + 16 * (g + t));
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bt[4 * t], acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bt[4 * t + 1], acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bt[4 * t + 2], acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bt[4 * t + 3], acc[r], 0, 0, 0);
+                }
             }
         }
     }
-    return acc;
 }
 
-template <int NA>  // NA = float4 loads per thread that cover the A tile: 16 * K / 4 <= NA * 256
+// NA = float4 loads per thread that cover 16 rows of the A tile (16 * K / 4 <= NA * 256);
+// TMT = 16-row tiles per workgroup (1: latency lane, 2: throughput lane).
+template <int NA, int TMT>
 __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
     const int local = blockIdx.x - T.tile0;
     const int tm = local / T.ntn, tn = local - tm * T.ntn;
-    const int row0 = tm * 16;
+    const int row0 = tm * 16 * TMT;
     const int K = T.K, N = T.N;
     const int S = K + 4;  // LDS row stride (floats)
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int flags = T.flags;
     const int WK = T.wk, NW = 4 / WK;
-    float* red = lds + 16 * S;  // [WK-1][NW][64] float4 partial accumulators
+    float* red = lds + 16 * TMT * S;  // [WK-1][NW][TMT][64] float4 partial accumulators
 #ifdef FQL_STAMPS
     unsigned long long stamp[8];
     int nst = 0;
@@ -280,9 +287,9 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
 #define STAMP() do {} while (0)
 #endif
 
-    // ---- issue every independent load of the tile up front: the A tile (<= 16 x 16 B per thread), the
-    // wave's first two B chunks and its bias.  At one wave per SIMD only explicit parallel issue hides
-    // the ~0.3-1.5 us (cold, cross-XCD) load latency; a rolled staging loop would serialise it.
+    // ---- issue every independent load of the tile up front: the A tile (<= 16 x 16 B per thread and row
+    // tile), the wave's first two B chunks and its bias.  At one wave per SIMD only explicit parallel issue
+    // hides the ~0.3-1.5 us (cold, cross-XCD) load latency; a rolled staging loop would serialise it.
     const int nt = wave % NW, kp = wave / NW;
     const int n0 = (tn * NW + nt) * 16;
     const int c = lane & 15, q = lane >> 4;
@@ -293,36 +300,39 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
     const int k4 = K >> 2;
     const int nA = 16 * k4;
     float b0[32], b1[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) { b0[i] = 0.f; b1[i] = 0.f; }  // defined on every path: keeps them in VGPRs
     BAddr ba = transb ? gemm_baddr<true>(T, n0, c, q) : gemm_baddr<false>(T, n0, c, q);
     float bias = 0.f;
-    if (active) {
-        const int nfull = (gend - gbeg) >> 3;
-        if (transb) {
-            if (nfull > 0) gemm_load_chunk<true>(b0, ba.base + (size_t)(16 * gbeg) * ba.kstep, ba.ldb);
-            if (nfull > 1) gemm_load_chunk<true>(b1, ba.base + (size_t)(16 * (gbeg + 8)) * ba.kstep, ba.ldb);
-        } else {
-            if (nfull > 0) gemm_load_chunk<false>(b0, ba.base + (size_t)(16 * gbeg) * ba.kstep, ba.ldb);
-            if (nfull > 1) gemm_load_chunk<false>(b1, ba.base + (size_t)(16 * (gbeg + 8)) * ba.kstep, ba.ldb);
-        }
-        if ((flags & GF_BIAS) && kp == 0) bias = ldg(T.bias + n0 + c);
-    }
-    {
+#pragma unroll
+    for (int pass = 0; pass < TMT; ++pass) {
         f32x4 av[NA];
-        const float* __restrict__ Ag = T.A + (size_t)row0 * T.lda;
+        const float* __restrict__ Ag = T.A + (size_t)(row0 + 16 * pass) * T.lda;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int f = min(tid + i * FQL_THREADS, nA - 1);  // clamped, unconditional
             const int r = f / k4, kk = f - r * k4;
             av[i] = ldg4(Ag + (size_t)r * T.lda + 4 * kk);
         }
+        if (pass == 0) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) { b0[i] = 0.f; b1[i] = 0.f; }  // defined on every path: stay in VGPRs
+            if (active) {
+                const int nfull = (gend - gbeg) >> 3;
+                if (transb) {
+                    if (nfull > 0) gemm_load_chunk<true>(b0, ba.base + (size_t)(16 * gbeg) * ba.kstep, ba.ldb);
+                    if (nfull > 1) gemm_load_chunk<true>(b1, ba.base + (size_t)(16 * (gbeg + 8)) * ba.kstep, ba.ldb);
+                } else {
+                    if (nfull > 0) gemm_load_chunk<false>(b0, ba.base + (size_t)(16 * gbeg) * ba.kstep, ba.ldb);
+                    if (nfull > 1) gemm_load_chunk<false>(b1, ba.base + (size_t)(16 * (gbeg + 8)) * ba.kstep, ba.ldb);
+                }
+                if ((flags & GF_BIAS) && kp == 0) bias = ldg(T.bias + n0 + c);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int f = tid + i * FQL_THREADS;
             if (f < nA) {
                 const int r = f / k4, kk = f - r * k4;
-                *reinterpret_cast<f32x4*>(&lds[r * S + 4 * kk]) = av[i];
+                *reinterpret_cast<f32x4*>(&lds[(16 * pass + r) * S + 4 * kk]) = av[i];
             }
         }
     }
@@ -331,58 +341,71 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
     STAMP();
     if (flags & GF_A_LN) {
         // 16 threads per row; flax LayerNorm: eps 1e-6, var = max(0, E[x^2] - E[x]^2)
-        const int r = tid >> 4, j = tid & 15;
+        const int j = tid & 15;
         const int width = T.ln_width;
-        float s = 0.f, s2 = 0.f;
-        for (int k = j; k < width; k += 16) {
-            const float v = lds[r * S + k];
-            s += v; s2 += v * v;
-        }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            s += __shfl_xor(s, o);
-            s2 += __shfl_xor(s2, o);
-        }
-        const float inv = 1.0f / (float)width;
-        const float mean = s * inv;
-        const float var = fmaxf(0.0f, s2 * inv - mean * mean);
-        const float rstd = 1.0f / sqrtf(var + 1e-6f);
         const bool wr = (flags & GF_LN_WRITE) && tn == 0;
-        for (int k = j; k < K; k += 16) {
-            float v = 0.f;
-            if (k < width) v = (lds[r * S + k] - mean) * rstd * ldg(T.ln_g + k) + ldg(T.ln_b + k);
-            lds[r * S + k] = v;
-            if (wr) stg(T.ln_xout + (size_t)(row0 + r) * T.lda + k, v);
-        }
-        if (wr && j == 0) {
-            T.ln_stats[2 * (row0 + r)] = mean;
-            T.ln_stats[2 * (row0 + r) + 1] = rstd;
+#pragma unroll
+        for (int pass = 0; pass < TMT; ++pass) {
+            const int r = 16 * pass + (tid >> 4);
+            float s = 0.f, s2 = 0.f;
+            for (int k = j; k < width; k += 16) {
+                const float v = lds[r * S + k];
+                s += v; s2 += v * v;
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                s += __shfl_xor(s, o);
+                s2 += __shfl_xor(s2, o);
+            }
+            const float inv = 1.0f / (float)width;
+            const float mean = s * inv;
+            const float var = fmaxf(0.0f, s2 * inv - mean * mean);
+            const float rstd = 1.0f / sqrtf(var + 1e-6f);
+            for (int k = j; k < K; k += 16) {
+                float v = 0.f;
+                if (k < width) v = (lds[r * S + k] - mean) * rstd * ldg(T.ln_g + k) + ldg(T.ln_b + k);
+                lds[r * S + k] = v;
+                if (wr) stg(T.ln_xout + (size_t)(row0 + r) * T.lda + k, v);
+            }
+            if (wr && j == 0) {
+                stg(T.ln_stats + 2 * (row0 + r), mean);
+                stg(T.ln_stats + 2 * (row0 + r) + 1, rstd);
+            }
         }
         __syncthreads();
     }
 
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (active)
-        acc = transb ? gemm_wave<true>(ba, lds, S, gbeg, gend, c, q, b0, b1) : gemm_wave<false>(ba, lds, S, gbeg, gend, c, q, b0, b1);
+    f32x4 acc[TMT];
+#pragma unroll
+    for (int r = 0; r < TMT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        if (transb) gemm_wave<true, TMT>(acc, ba, lds, S, gbeg, gend, c, q, b0, b1);
+        else gemm_wave<false, TMT>(acc, ba, lds, S, gbeg, gend, c, q, b0, b1);
+    }
     STAMP();
     if (WK > 1) {
-        if (kp > 0) *reinterpret_cast<f32x4*>(&red[(((kp - 1) * NW + nt) * 64 + lane) * 4]) = acc;
+        if (kp > 0) {
+#pragma unroll
+            for (int r = 0; r < TMT; ++r) *reinterpret_cast<f32x4*>(&red[((((kp - 1) * NW + nt) * TMT + r) * 64 + lane) * 4]) = acc[r];
+        }
         __syncthreads();
         if (kp > 0) return;
-        for (int p = 1; p < WK; ++p) acc += *reinterpret_cast<const f32x4*>(&red[(((p - 1) * NW + nt) * 64 + lane) * 4]);
+        for (int p = 1; p < WK; ++p) {
+#pragma unroll
+            for (int r = 0; r < TMT; ++r) acc[r] += *reinterpret_cast<const f32x4*>(&red[((((p - 1) * NW + nt) * TMT + r) * 64 + lane) * 4]);
+        }
     }
     if (!active) return;
     STAMP();
-#ifdef FQL_STAMPS
-    const int FQL_STAMP_EPILOGUE = 1;
-#endif
 
     // ---- epilogue. C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
     const int n = n0 + c;
 #pragma unroll
+    for (int rt = 0; rt < TMT; ++rt) {
+#pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int row = row0 + 4 * q + i;
-        float v = acc[i] + bias;
+        const int row = row0 + 16 * rt + 4 * q + i;
+        float v = acc[rt][i] + bias;
         const size_t o = (size_t)row * T.ldc + n;
         if (flags & GF_EULER) {
             // agents/fql.py:166-169: actions = actions + vels / flow_steps ; t = (i+1)/flow_steps
@@ -401,6 +424,7 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
         if (flags & GF_CLIP_OUT) v = clip1(v);
         stg(T.C + o, v);
     }
+    }
 #ifdef FQL_STAMPS
     STAMP();
     if (lane == 0 && wave == 0 && T.aux) {
@@ -410,13 +434,25 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
 #endif
 }
 
-__global__ __launch_bounds__(FQL_THREADS) void fql_gemm16_kernel(const GemmTask* __restrict__ tasks, int ntasks) {
+// TMT2: the launch contains tasks with two row tiles per workgroup; KBIG: some task has K > 512.  Separate
+// kernels so the common case (K <= 512) keeps its register count (and with it two workgroups per CU).
+#ifndef FQL_GEMM_WAVES
+#define FQL_GEMM_WAVES 1
+#endif
+template <bool TMT2, bool KBIG>
+__global__ __launch_bounds__(FQL_THREADS, FQL_GEMM_WAVES) void fql_gemm16_kernel(const GemmTask* __restrict__ tasks, int ntasks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int ti = find_task(tasks, ntasks, blockIdx.x);
     const GemmTask& T = tasks[ti];
-    if (T.K <= 128) gemm16_body<2>(T, lds);
-    else if (T.K <= 512) gemm16_body<8>(T, lds);
-    else gemm16_body<16>(T, lds);
+    if (TMT2 && T.tmt == 2) {
+        if (T.K <= 128) gemm16_body<2, 2>(T, lds);
+        else if (!KBIG || T.K <= 512) gemm16_body<8, 2>(T, lds);
+        else gemm16_body<16, 2>(T, lds);
+    } else {
+        if (T.K <= 128) gemm16_body<2, 1>(T, lds);
+        else if (!KBIG || T.K <= 512) gemm16_body<8, 1>(T, lds);
+        else gemm16_body<16, 1>(T, lds);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
