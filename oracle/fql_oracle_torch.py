@@ -138,7 +138,7 @@ class TorchFQL:
         cfg = self.config
         loss, info, grads = self.grads(batch, noise)
         leaves = [g for _, g in tree_leaves_with_path(grads)]
-        info = {k: float(v) for k, v in info.items()}
+        info = {k: float(v.detach()) for k, v in info.items()}
         info['grad/max'] = max(float(g.max()) for g in leaves)
         info['grad/min'] = min(float(g.min()) for g in leaves)
         info['grad/norm'] = float(sum(torch.linalg.norm(g.reshape(-1)) for g in leaves))

@@ -1,0 +1,60 @@
+"""CPU: the oracle reproduces the committed golden vectors (tests/golden/*.npz, made by make_golden.py)."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fql_oracle as O
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', '*.npz')))
+
+
+def load_case(path):
+    z = np.load(path, allow_pickle=False)
+    meta = json.loads(str(z['meta']))
+    cfg = O.get_config()
+    cfg.update(actor_hidden_dims=tuple(meta['hidden']), value_hidden_dims=tuple(meta['hidden']), batch_size=meta['B'])
+    cfg.update(meta['cfg'])
+
+    def tree(prefix):
+        t = {}
+        for k in z.files:
+            if k.startswith(prefix + '/'):
+                node = t
+                keys = k[len(prefix) + 1:].split('/')
+                for kk in keys[:-1]:
+                    node = node.setdefault(kk, {})
+                node[keys[-1]] = z[k]
+        return t
+
+    return dict(meta=meta, cfg=cfg, params=tree('params'), grads=tree('grads'), new_params=tree('new_params'),
+                batch={k[6:]: z[k] for k in z.files if k.startswith('batch/')},
+                noise={k[6:]: z[k] for k in z.files if k.startswith('noise/')},
+                total_loss=float(z['total_loss']), info_total_loss=z['info_total_loss'], info_update=z['info_update'],
+                sample_actions=z['sample_actions'], flow_actions=z['flow_actions'])
+
+
+def test_golden_files_present():
+    assert len(GOLDEN) >= 3
+
+
+@pytest.mark.parametrize('path', GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+@pytest.mark.parametrize('dtype,rtol', [(np.float64, 1e-6), (np.float32, 2e-4)])
+def test_oracle_reproduces_golden(path, dtype, rtol):
+    c = load_case(path)
+    m = c['meta']
+    ref = O.OracleFQL(c['params'], c['cfg'], m['obs_dim'], m['act_dim'], dtype)
+    loss, info = ref.total_loss(c['batch'], c['noise'])
+    assert abs(float(loss) - c['total_loss']) <= rtol * max(1, abs(c['total_loss']))
+    for i, k in enumerate(O.INFO_KEYS[:10]):
+        assert abs(float(info[k]) - c['info_total_loss'][i]) <= rtol * max(1, abs(c['info_total_loss'][i])), k
+    _, _, g = ref.grads(c['batch'], c['noise'])
+    for (p, a), (_, b) in zip(O.tree_leaves_with_path(g), O.tree_leaves_with_path(c['grads'])):
+        np.testing.assert_allclose(a, b, rtol=0, atol=rtol * max(np.abs(b).max(), 1e-6) * 5, err_msg=p)
+    np.testing.assert_allclose(ref.sample_actions(c['batch']['observations'], c['noise']['eps2']), c['sample_actions'], atol=1e-5)
+    np.testing.assert_allclose(ref.compute_flow_actions(c['batch']['observations'], c['noise']['z']), c['flow_actions'], atol=2e-5)
+    _, iu = ref.update(c['batch'], c['noise'])
+    for i, k in enumerate(O.INFO_KEYS):
+        assert abs(iu[k] - c['info_update'][i]) <= rtol * max(1, abs(c['info_update'][i])), k

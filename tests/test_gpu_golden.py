@@ -1,0 +1,31 @@
+"""GPU: the HIP engine (through the C ABI) reproduces the committed golden vectors."""
+import numpy as np
+import pytest
+
+from oracle import fql_oracle as O
+from tests.test_golden_oracle import GOLDEN, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('path', GOLDEN)
+def test_engine_reproduces_golden(path):
+    import fql_amd
+    c = load_case(path)
+    m = c['meta']
+    cfg = fql_amd.get_config()
+    cfg.update({k: v for k, v in c['cfg'].items() if k in cfg})
+    agent = fql_amd.FQLAgent.create(0, c['batch']['observations'][:1], c['batch']['actions'][:1], cfg)
+    agent.set_params(c['params'])
+    loss, info = agent.total_loss(c['batch'], noise=c['noise'])
+    assert abs(loss - c['total_loss']) <= 2e-6 + 2e-5 * abs(c['total_loss'])
+    for i, k in enumerate(O.INFO_KEYS[:10]):
+        assert abs(info[k] - c['info_total_loss'][i]) <= 2e-6 + 2e-5 * abs(c['info_total_loss'][i]), k
+    np.testing.assert_allclose(agent.sample_actions(c['batch']['observations'], noises=c['noise']['eps2']), c['sample_actions'], atol=2e-6)
+    np.testing.assert_allclose(agent.compute_flow_actions(c['batch']['observations'], c['noise']['z']), c['flow_actions'], atol=5e-6)
+    _, iu = agent.update(c['batch'], noise=c['noise'])
+    for i, k in enumerate(O.INFO_KEYS):
+        assert abs(iu[k] - c['info_update'][i]) <= 5e-6 + 5e-5 * abs(c['info_update'][i]), k
+    mu = dict(O.tree_leaves_with_path(agent.get_opt_state()['mu']))
+    for p, g in O.tree_leaves_with_path(c['grads']):
+        np.testing.assert_allclose(mu[p] / 0.1, g, rtol=0, atol=2e-5 * np.abs(g).max() + 1e-9, err_msg=p)
