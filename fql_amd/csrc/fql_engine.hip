@@ -24,6 +24,8 @@
 #include <string>
 #include <vector>
 
+#define FQL_LANES 4
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -89,7 +91,7 @@ struct Leaf {
 // ------------------------------------------------------------------------------------------------
 // program = ordered ops with read/write sets -> levels -> launches
 // ------------------------------------------------------------------------------------------------
-enum OpType { OP_GEMM, OP_WGRAD, OP_LNBWD, OP_PREP, OP_POSTOS, OP_LOSS_CRITIC, OP_LOSS_Q, OP_LOSS_BC,
+enum OpType { OP_GEMM, OP_GEMM64, OP_WGRAD, OP_LNBWD, OP_PREP, OP_POSTOS, OP_LOSS_CRITIC, OP_LOSS_Q, OP_LOSS_BC,
               OP_LOSS_ACTOR, OP_BEGIN, OP_ADAM, OP_FINALIZE };
 
 struct Op {
@@ -126,8 +128,9 @@ struct Launch {
 struct Program {
     std::vector<Op> ops;
     std::vector<Launch> launches;
-    bool two_lanes = false;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool two_lanes = false;  // more than one lane in use
+    bool lane_used[FQL_LANES] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[FQL_LANES] = {};
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     int64_t macs = 0;
@@ -138,6 +141,7 @@ struct PassBuf {
     const void* id = nullptr;          // dependency id base
     float* x0 = nullptr;               // [M, in_p]
     std::vector<float*> g, xn, z, stats;  // per hidden layer
+    std::vector<float*> lnpart;        // LN layers: per-row partial sums per 64-column tile (gemm64 path)
     float* out = nullptr;              // [M, out_p]
     std::vector<float*> dz;            // per layer gradient wrt pre-activation / output
     std::vector<float*> dy;            // LN nets: gradient wrt LN output
@@ -150,7 +154,8 @@ struct fql_engine {
     fql_config cfg{};
     uint64_t seed = 0;
     int device = 0;
-    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, stream4 = nullptr;
+    bool allow64 = true;
     int emit_lane = 0;
     std::string err;
 
@@ -218,7 +223,7 @@ struct fql_engine {
                 Layer L{};
                 L.in = prev;
                 L.out = (i < nh) ? hid[i] : out;
-                L.in_p = pad16(L.in);
+                L.in_p = (i == 0) ? ((L.in + 63) & ~63) : pad16(L.in);
                 L.out_p = pad16(L.out);
                 L.ln = ln && i < nh;
                 n.layers.push_back(L);
@@ -370,9 +375,11 @@ struct fql_engine {
             if (n.layers[l].ln) {
                 p.xn.push_back(dalloc(owner, (size_t)M * H));
                 p.stats.push_back(dalloc(owner, (size_t)M * 2));
+                p.lnpart.push_back(dalloc(owner, (size_t)M * ((2 * ((H + 63) / 64) + 3) & ~3)));
             } else {
                 p.xn.push_back(p.g.back());
                 p.stats.push_back(nullptr);
+                p.lnpart.push_back(nullptr);
             }
         }
         p.out = dalloc(owner, (size_t)M * n.layers[L].out_p);
@@ -382,6 +389,25 @@ struct fql_engine {
             if (input_grad) p.dx0 = dalloc(owner, (size_t)M * n.in_p());
         }
         return p;
+    }
+
+    // throughput-lane tasks with 64-aligned shapes go to the 64x64 LDS-tiled kernel
+    bool want64(int M, int N, int K, int flags) const {
+        static const bool off = getenv("FQL_NO_GEMM64") != nullptr;
+        if (off || emit_lane == 0 || !allow64) return false;
+        if (M % 64 || N % 64 || K % 64) return false;
+        if (flags & (GF_EULER | GF_CLIP_OUT)) return false;
+        return true;
+    }
+
+    // per-pass placement: lane and kernel family (env overrides FQL_LANE_<pass>, FQL_K16_<pass> for experiments)
+    void place(const char* pass, int default_lane, bool default64) {
+        char key[64];
+        snprintf(key, sizeof key, "FQL_LANE_%s", pass);
+        const char* e = getenv(key);
+        emit_lane = e ? atoi(e) : default_lane;
+        snprintf(key, sizeof key, "FQL_K16_%s", pass);
+        allow64 = getenv(key) ? false : default64;
     }
 
     void push(Program& pr, Op& op) {
@@ -424,6 +450,11 @@ struct fql_engine {
                 t.flags |= GF_GELU;
                 if (save) { t.flags |= GF_SAVE_Z; t.Zout = p.z[l]; op.writes.push_back(t.Zout); }
                 op.writes.push_back(t.C);
+                if (want64(t.M, t.N, t.K, t.flags)) {
+                    op.type = OP_GEMM64;
+                    if (a_ln) { t.aux2 = p.lnpart[l - 1]; t.i0 = t.K / 64; op.reads.push_back(t.aux2); }
+                    if (ly.ln) { t.flags |= GF_LN_PART; t.aux = p.lnpart[l]; t.i1 = t.N / 64; op.writes.push_back(t.aux); }
+                }
             } else {
                 t.C = p.out;
                 t.flags |= final_flags;
@@ -464,7 +495,12 @@ struct fql_engine {
                 w.M = M; w.Kin = ly.in_p; w.N = ly.out_p;
                 op.reads = {xin_id, dz};
                 op.writes = {w.dW, w.db};
+                // weight gradients feed nothing but the optimizer: background lane
+                const int keep = emit_lane;
+                static const bool wlane = getenv("FQL_NO_WLANE") == nullptr;
+                if (wlane) emit_lane = 2;
                 push(pr, op);
+                emit_lane = keep;
             }
             if (l == 0 && !input_grad) break;
             // dgrad: dX = dZ W^T
@@ -487,6 +523,7 @@ struct fql_engine {
             if (prev.ln) {
                 t.C = p.dy[l - 1];
                 op.writes = {t.C};
+                if (want64(t.M, t.N, t.K, t.flags)) op.type = OP_GEMM64;
                 push(pr, op);
                 Op lo{};
                 lo.type = OP_LNBWD;
@@ -509,6 +546,7 @@ struct fql_engine {
                 t.Zprev = rows(p.z[l - 1], prev.out_p);
                 op.reads.push_back(p.z[l - 1]);
                 op.writes = {t.C};
+                if (want64(t.M, t.N, t.K, t.flags)) op.type = OP_GEMM64;
                 push(pr, op);
             }
         }
@@ -517,7 +555,7 @@ struct fql_engine {
     // ---------------------------------------------------------------------------------------
     // scheduling + launch tables + graph capture
     // ---------------------------------------------------------------------------------------
-    static bool is_table(OpType t) { return t == OP_GEMM || t == OP_WGRAD || t == OP_LNBWD; }
+    static bool is_table(OpType t) { return t == OP_GEMM || t == OP_GEMM64 || t == OP_WGRAD || t == OP_LNBWD; }
 
     void schedule(Program& pr, std::vector<void*>& owner) {
         // list scheduling: level = 1 + max level of every op this one conflicts with (RAW, WAW, WAR)
@@ -549,9 +587,10 @@ struct fql_engine {
         for (const Op& op : pr.ops) maxlv = std::max(maxlv, op.level);
         pr.launches.clear();
         pr.two_lanes = false;
+        for (bool& b : pr.lane_used) b = false;
         std::vector<int> launch_of(pr.ops.size(), -1);
         for (int lv = 0; lv <= maxlv; ++lv) {
-          for (int lane = 0; lane < 2; ++lane) {
+          for (int lane = 0; lane < FQL_LANES; ++lane) {
             for (int ty = 0; ty <= OP_FINALIZE; ++ty) {
                 std::vector<const Op*> sel;
                 for (int oi = 0; oi < (int)pr.ops.size(); ++oi) {
@@ -559,7 +598,8 @@ struct fql_engine {
                     if (op.level == lv && op.type == ty && op.lane == lane) sel.push_back(&op);
                 }
                 if (sel.empty()) continue;
-                if (lane == 1) pr.two_lanes = true;
+                if (lane >= 1) pr.two_lanes = true;
+                pr.lane_used[lane] = true;
                 if (!is_table((OpType)ty)) {
                     for (const Op* o : sel) {
                         Launch L;
@@ -581,7 +621,7 @@ struct fql_engine {
                     std::vector<GemmTask> tb;
                     for (const Op* o : sel) {
                         GemmTask t = o->gemm;
-                        static const int tmt_side = getenv("FQL_TMT") ? atoi(getenv("FQL_TMT")) : 2;
+                        static const int tmt_side = getenv("FQL_TMT") ? atoi(getenv("FQL_TMT")) : 1;
                         t.wk = (t.N <= 16) ? 4 : 2;
                         // throughput lane: two 16-row tiles per workgroup share each B fragment
                         t.tmt = (lane == 1 && tmt_side == 2 && t.M % 32 == 0 && t.M >= 256 && t.N >= 32) ? 2 : 1;
@@ -593,6 +633,19 @@ struct fql_engine {
                         L.lds = std::max(L.lds, ((size_t)16 * t.tmt * (t.K + 4) + 1024 * t.tmt) * sizeof(float));
                         tb.push_back(t);
                     }
+                    L.table = dalloc(owner, tb.size() * sizeof(GemmTask) / sizeof(float) + 4);
+                    HIP_CHECK(hipMemcpy(L.table, tb.data(), tb.size() * sizeof(GemmTask), hipMemcpyHostToDevice));
+                } else if (ty == OP_GEMM64) {
+                    std::vector<GemmTask> tb;
+                    for (const Op* o : sel) {
+                        GemmTask t = o->gemm;
+                        t.wk = 1; t.tmt = 4;
+                        t.ntn = t.N / 64;
+                        t.tile0 = tile;
+                        tile += (t.M / 64) * t.ntn;
+                        tb.push_back(t);
+                    }
+                    L.lds = (size_t)(4 * 64 * 68 + 256) * sizeof(float);
                     L.table = dalloc(owner, tb.size() * sizeof(GemmTask) / sizeof(float) + 4);
                     HIP_CHECK(hipMemcpy(L.table, tb.data(), tb.size() * sizeof(GemmTask), hipMemcpyHostToDevice));
                 } else if (ty == OP_WGRAD) {
@@ -625,45 +678,54 @@ struct fql_engine {
         }
         // cross-lane edges: a launch waits for the latest launch of the other lane it depends on (lane streams
         // are in-order, so that covers the earlier ones); skip waits already implied by an earlier wait.
-        int waited_upto[2] = {-1, -1};  // per waiting lane: highest other-lane launch index already waited for
+        int waited_upto[FQL_LANES][FQL_LANES];  // [waiting lane][other lane]: highest launch index already waited for
+        for (auto& r : waited_upto) for (int& v : r) v = -1;
         for (int li = 0; li < (int)pr.launches.size(); ++li) {
             Launch& L = pr.launches[li];
-            int need = -1;
+            int need[FQL_LANES];
+            for (int& v : need) v = -1;
             for (int oi = 0; oi < (int)pr.ops.size(); ++oi) {
                 if (launch_of[oi] != li) continue;
                 for (int d : pr.ops[oi].deps) {
                     const int dl = launch_of[d];
-                    if (pr.launches[dl].lane != L.lane) need = std::max(need, dl);
+                    const int ol = pr.launches[dl].lane;
+                    if (ol != L.lane) need[ol] = std::max(need[ol], dl);
                 }
             }
-            if (need > waited_upto[L.lane]) {
-                L.waits.push_back(need);
-                pr.launches[need].record_after = true;
-                waited_upto[L.lane] = need;
-            }
+            for (int ol = 0; ol < FQL_LANES; ++ol)
+                if (need[ol] > waited_upto[L.lane][ol]) {
+                    L.waits.push_back(need[ol]);
+                    pr.launches[need[ol]].record_after = true;
+                    waited_upto[L.lane][ol] = need[ol];
+                }
         }
     }
 
     // s2 != nullptr: two-stream issue (graph capture of a two-lane program); otherwise everything goes to `s0` in
     // emission order, which is a topological order of the program.
-    void run_launches(Program& pr, hipStream_t s0, hipStream_t s2 = nullptr) {
-        const bool par = s2 != nullptr && pr.two_lanes;
+    void run_launches(Program& pr, hipStream_t s0, bool fork = false) {
+        const bool par = fork && pr.two_lanes;
+        hipStream_t ls[FQL_LANES] = {s0, stream2, stream3, stream4};
         if (par) {
             if (!pr.ev_fork) HIP_CHECK(hipEventCreateWithFlags(&pr.ev_fork, hipEventDisableTiming));
-            if (!pr.ev_join) HIP_CHECK(hipEventCreateWithFlags(&pr.ev_join, hipEventDisableTiming));
             HIP_CHECK(hipEventRecord(pr.ev_fork, s0));
-            HIP_CHECK(hipStreamWaitEvent(s2, pr.ev_fork, 0));
+            for (int l = 1; l < FQL_LANES; ++l) if (pr.lane_used[l]) HIP_CHECK(hipStreamWaitEvent(ls[l], pr.ev_fork, 0));
         }
+        static const int only_lane = getenv("FQL_ONLY_LANE") ? atoi(getenv("FQL_ONLY_LANE")) : -1;  // timing experiments
         for (Launch& L : pr.launches) {
-            hipStream_t s = (par && L.lane == 1) ? s2 : s0;
+            if (only_lane >= 0 && pr.two_lanes && L.lane != only_lane) continue;
+            hipStream_t s = par ? ls[L.lane] : s0;
             if (par)
-                for (int w : L.waits) HIP_CHECK(hipStreamWaitEvent(s, pr.launches[w].ev, 0));
+                for (int w : L.waits) if (pr.launches[w].ev) HIP_CHECK(hipStreamWaitEvent(s, pr.launches[w].ev, 0));
             switch (L.type) {
                 case OP_GEMM:
                     if (L.tmt2 && L.kbig) hipLaunchKernelGGL((fql_gemm16_kernel<true, true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
                     else if (L.tmt2) hipLaunchKernelGGL((fql_gemm16_kernel<true, false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
                     else if (L.kbig) hipLaunchKernelGGL((fql_gemm16_kernel<false, true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
                     else hipLaunchKernelGGL((fql_gemm16_kernel<false, false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
+                    break;
+                case OP_GEMM64:
+                    hipLaunchKernelGGL(fql_gemm64_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
                     break;
                 case OP_WGRAD:
                     hipLaunchKernelGGL(fql_wgrad_kernel, dim3(L.grid), dim3(FQL_THREADS), 0, s, (const WgradTask*)L.table, L.ntasks);
@@ -706,10 +768,13 @@ struct fql_engine {
                 HIP_CHECK(hipEventRecord(L.ev, s));
             }
         }
-        if (par) {
-            HIP_CHECK(hipEventRecord(pr.ev_join, s2));
-            HIP_CHECK(hipStreamWaitEvent(s0, pr.ev_join, 0));
-        }
+        if (par)
+            for (int l = 1; l < FQL_LANES; ++l) {
+                if (!pr.lane_used[l]) continue;
+                if (!pr.ev_join[l]) HIP_CHECK(hipEventCreateWithFlags(&pr.ev_join[l], hipEventDisableTiming));
+                HIP_CHECK(hipEventRecord(pr.ev_join[l], ls[l]));
+                HIP_CHECK(hipStreamWaitEvent(s0, pr.ev_join[l], 0));
+            }
         HIP_CHECK(hipGetLastError());
     }
 
@@ -719,7 +784,7 @@ struct fql_engine {
         HIP_CHECK(hipStreamSynchronize(stream));
         HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
         try {
-            run_launches(pr, stream, stream2);
+            run_launches(pr, stream, true);
         } catch (...) {
             hipGraph_t g = nullptr;
             hipStreamEndCapture(stream, &g);
@@ -735,7 +800,7 @@ struct fql_engine {
         if (pr.graph) hipGraphDestroy(pr.graph);
         for (Launch& L : pr.launches) if (L.ev) hipEventDestroy(L.ev);
         if (pr.ev_fork) hipEventDestroy(pr.ev_fork);
-        if (pr.ev_join) hipEventDestroy(pr.ev_join);
+        for (hipEvent_t e : pr.ev_join) if (e) hipEventDestroy(e);
         pr = Program{};
     }
 
@@ -748,6 +813,7 @@ struct fql_engine {
         const int ap = pad16(ad);
         DevState* st = d_state;
         const void* INFO = &st->info[0];
+        const void *I_CR = &st->info[0], *I_BC = &st->info[5], *I_Q = &st->info[7], *I_MSE = &st->info[9], *I_ACT = &st->info[4];
         // Lane 0 carries the critical path (prep -> Euler chain -> actor loss -> one-step backward); the rest of
         // the step runs beside it on lane 1 (a second graph branch) and only meets it at the actor loss.
         emit_lane = 0;
@@ -758,7 +824,7 @@ struct fql_engine {
             op.writes = {X_os, X_bc, X_eu, X_c1, X_c2, X_ct, vel, w_rew, w_mask, w_act};
             push(pr, op);
         }
-        emit_lane = 1;
+        place("os", 1, true);
         // one-step actor on [next_obs|eps1 ; obs|z ; obs|eps2]  (agents/fql.py:25,65,82)
         emit_forward(pr, p_os, with_grads);
         {
@@ -766,12 +832,15 @@ struct fql_engine {
             op.type = OP_POSTOS;
             op.postos = PostOsArgs{p_os.out, w_act, X_ct, X_c2, st, B, od, ad, inp_c, ap};
             op.reads = {p_os.out, w_act};
-            op.writes = {X_ct, X_c2, INFO};
+            op.writes = {X_ct, X_c2, I_MSE};
             push(pr, op);
         }
+        place("c1", 1, true);
         // critic(obs, actions) with grad params; target critic(next_obs, next_actions)  (fql.py:28,36)
         for (int e = 0; e < 2; ++e) emit_forward(pr, p_c1[e], with_grads);
+        place("ct", 1, true);
         for (int e = 0; e < 2; ++e) emit_forward(pr, p_ct[e], false);
+        place("c1", 1, true);
         {
             Op op{};
             op.type = OP_LOSS_CRITIC;
@@ -779,25 +848,27 @@ struct fql_engine {
                                    with_grads ? p_c1[0].dz.back() : nullptr, with_grads ? p_c1[1].dz.back() : nullptr,
                                    st, B, cfg.q_agg, with_grads ? 1 : 0, cfg.discount};
             op.reads = {p_c1[0].out, p_c1[1].out, p_ct[0].out, p_ct[1].out, w_rew, w_mask};
-            op.writes = {INFO};
+            op.writes = {I_CR};
             if (with_grads) { op.writes.push_back(p_c1[0].dz.back()); op.writes.push_back(p_c1[1].dz.back()); }
             push(pr, op);
         }
         if (with_grads)
             for (int e = 0; e < 2; ++e) emit_backward(pr, p_c1[e], 0, B, true, false);
         // BC flow-matching pass (fql.py:52-59)
+        place("bc", 1, true);
         emit_forward(pr, p_bc, with_grads);
         {
             Op op{};
             op.type = OP_LOSS_BC;
             op.lb = LossBcArgs{p_bc.out, vel, with_grads ? p_bc.dz.back() : nullptr, st, B, ad, ap, with_grads ? 1 : 0};
             op.reads = {p_bc.out, vel};
-            op.writes = {INFO};
+            op.writes = {I_BC};
             if (with_grads) op.writes.push_back(p_bc.dz.back());
             push(pr, op);
         }
         if (with_grads) emit_backward(pr, p_bc, 0, B, true, false);
         // Q term: critic(obs, clip(actor_actions)) with stored params, input-differentiable (fql.py:69-76)
+        place("c2", 1, true);
         for (int e = 0; e < 2; ++e) emit_forward(pr, p_c2[e], with_grads);
         {
             Op op{};
@@ -805,14 +876,14 @@ struct fql_engine {
             op.lq = LossQArgs{p_c2[0].out, p_c2[1].out, with_grads ? p_c2[0].dz.back() : nullptr,
                               with_grads ? p_c2[1].dz.back() : nullptr, st, B, cfg.normalize_q_loss, with_grads ? 1 : 0};
             op.reads = {p_c2[0].out, p_c2[1].out};
-            op.writes = {INFO};
+            op.writes = {I_Q};
             if (with_grads) { op.writes.push_back(p_c2[0].dz.back()); op.writes.push_back(p_c2[1].dz.back()); }
             push(pr, op);
         }
         if (with_grads)
             for (int e = 0; e < 2; ++e) emit_backward(pr, p_c2[e], 0, B, false, true);
         // Euler chain through the BC flow (fql.py:155-171): flow_steps sequential forwards
-        emit_lane = 0;
+        place("eu", 0, false);
         const int fs = cfg.flow_steps;
         for (int s = 0; s < fs; ++s)
             emit_forward(pr, p_eu, false, GF_EULER | (s == fs - 1 ? GF_EULER_LAST : 0), X_eu, tgt, 1.0f / (float)fs,
@@ -823,8 +894,8 @@ struct fql_engine {
             op.la = LossActorArgs{p_os.out + (size_t)B * ap, tgt, with_grads ? p_c2[0].dx0 : nullptr,
                                   with_grads ? p_c2[1].dx0 : nullptr, with_grads ? p_os_bwd.dz.back() : nullptr, st, B, od, ad,
                                   inp_c, ap, with_grads ? 1 : 0, cfg.alpha};
-            op.reads = {p_os.out, tgt, INFO};
-            op.writes = {INFO};
+            op.reads = {p_os.out, tgt, I_BC, I_Q};
+            op.writes = {I_ACT};
             if (with_grads) {
                 op.reads.push_back(p_c2[0].dx0); op.reads.push_back(p_c2[1].dx0);
                 op.writes.push_back(p_os_bwd.dz.back());
@@ -836,7 +907,7 @@ struct fql_engine {
             Op op{};
             op.type = OP_FINALIZE;
             op.fin_mode = 0;
-            op.reads = {INFO};
+            op.reads = {I_CR, I_BC, I_Q, I_MSE, I_ACT};
             op.writes = {INFO};
             push(pr, op);
         }
@@ -1133,8 +1204,11 @@ int fql_create(const fql_config* cfg, uint64_t seed, fql_handle* out) {
             delete h;
             return FQL_E_NODEVICE;
         }
+        // (stream priorities were tried for the lanes: no gain with two streams, a 4x slowdown with three)
         HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking));
         h->build_nets();
         HIP_CHECK(hipMalloc((void**)&h->P, h->n_total * sizeof(float)));
         HIP_CHECK(hipMalloc((void**)&h->G, h->n_train * sizeof(float)));
@@ -1177,6 +1251,8 @@ int fql_destroy(fql_handle h) {
     hipFree(h->ds_obs); hipFree(h->ds_act); hipFree(h->ds_rew); hipFree(h->ds_mask); hipFree(h->ds_nobs); hipFree(h->ds_row);
     if (h->stream) hipStreamDestroy(h->stream);
     if (h->stream2) hipStreamDestroy(h->stream2);
+    if (h->stream3) hipStreamDestroy(h->stream3);
+    if (h->stream4) hipStreamDestroy(h->stream4);
     delete h;
     return FQL_OK;
 }

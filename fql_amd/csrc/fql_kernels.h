@@ -37,6 +37,7 @@ enum : int {
     GF_EULER = 1 << 7,      // epilogue: a += v / flow_steps, t column := t_next    agents/fql.py:166-169
     GF_EULER_LAST = 1 << 8, // ... and store clip(a, -1, 1) as the distillation target  agents/fql.py:170
     GF_CLIP_OUT = 1 << 9,   // epilogue: C = clip(acc + bias, -1, 1)            agents/fql.py:152
+    GF_LN_PART = 1 << 10,   // gemm64 epilogue: per-row (sum, sum sq) of this 64-column tile -> aux[row][i1 tiles][2]
 };
 
 struct GemmTask {
@@ -50,8 +51,8 @@ struct GemmTask {
     const float* ln_b;  // [K]
     float* ln_xout;     // [M, K] lda   (GF_LN_WRITE)
     float* ln_stats;    // [M, 2]       (GF_LN_WRITE)
-    float* aux;         // GF_EULER: X_eu [M, ld = i0]
-    float* aux2;        // GF_EULER_LAST: target actions [M, 16]
+    float* aux;         // GF_EULER: X_eu [M, ld = i0];  gemm64 GF_LN_PART: partial sums out [M][i1][2]
+    float* aux2;        // GF_EULER_LAST: target actions [M, N];  gemm64 GF_A_LN: partial sums in [M][i0][2]
     int M, N, K;
     int lda, ldb, ldc;
     int ln_width;       // real (unpadded) width for LN statistics
@@ -89,14 +90,22 @@ struct LnBwdTask {
 // ------------------------------------------------------------------------------------------------
 // math helpers
 // ------------------------------------------------------------------------------------------------
+// tanh via one v_exp_f32 and one reciprocal: tanh(u) = sign(u) (1 - e) / (1 + e), e = exp(-2|u|) in (0, 1].
+// Absolute error ~1e-7 (an ulp of 1), which is what GELU / GELU' see; libm tanhf costs ~5x the instructions and
+// sat on the critical path of every layer epilogue.
+__device__ __forceinline__ float fast_tanh(float u) {
+    const float e = __expf(-2.0f * fabsf(u));
+    const float t = (1.0f - e) * __frcp_rn(1.0f + e);
+    return copysignf(t, u);
+}
 __device__ __forceinline__ float gelu_f(float x) {
     // flax nn.gelu (approximate=True): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
     const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    return 0.5f * x * (1.0f + tanhf(u));
+    return 0.5f * x * (1.0f + fast_tanh(u));
 }
 __device__ __forceinline__ float gelu_grad_f(float x) {
     const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    const float th = tanhf(u);
+    const float th = fast_tanh(u);
     const float du = 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
     return 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * du;
 }
@@ -456,6 +465,205 @@ __global__ __launch_bounds__(FQL_THREADS, FQL_GEMM_WAVES) void fql_gemm16_kernel
 }
 
 // ------------------------------------------------------------------------------------------------
+// Throughput lane GEMM: 64 x 64 output tile per workgroup, K streamed through LDS in 64-deep chunks
+// (double buffered: chunk i+1 travels global -> VGPR while chunk i feeds the matrix cores), each wave a
+// 32 x 32 sub-tile = 2 x 2 MFMA tiles with independent accumulators.  0.125 B of L2 traffic per MAC (the
+// 16-row latency kernel needs 0.37) and 64 MFMAs per wave per chunk behind one barrier.
+// LayerNorm on the A operand needs whole-row statistics while A arrives in K chunks, so the PRODUCING layer
+// emits per-row partial sums (sum, sum of squares) per 64-column tile (GF_LN_PART) and the consumer folds
+// them in fixed order (deterministic) into mean / rstd before staging (utils/networks.py:58).
+// ------------------------------------------------------------------------------------------------
+#define G64_S 68  // LDS row stride (floats): 64 + 4, keeps 16-byte alignment and spreads banks
+template <bool transb>
+__device__ __forceinline__ void gemm64_body(const GemmTask& T, float* lds) {
+    float* As = lds;                    // [2][64][G64_S]
+    float* Bs = lds + 2 * 64 * G64_S;   // [2][64][G64_S]   ([k][n], or [n][k] when GF_TRANS_B)
+    float* part = Bs + 2 * 64 * G64_S;  // [2][64][2] LN partial sums of the epilogue
+    const int local = blockIdx.x - T.tile0;
+    const int tm = local / T.ntn, tn = local - tm * T.ntn;
+    const int row0 = tm * 64, n0 = tn * 64;
+    const int K = T.K;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int c = lane & 15, q = lane >> 4;
+    const int flags = T.flags;
+    const bool a_ln = (flags & GF_A_LN) != 0;
+    const bool ln_wr = (flags & GF_LN_WRITE) && tn == 0;
+    // staging coordinates: 4 float4 per thread per operand; f = tid + 256 i -> row f / 16, float4 column f % 16
+    const int sr = tid >> 4, sc4 = tid & 15;
+    float mean[4] = {0.f, 0.f, 0.f, 0.f}, rstd[4] = {1.f, 1.f, 1.f, 1.f};
+    if (a_ln) {
+        const int ntin = T.i0;  // 64-column tiles of the producing layer (<= 16: widths <= 1024)
+        const float inv = 1.0f / (float)T.ln_width;
+        f32x4 pv[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* pp = T.aux2 + (size_t)(row0 + sr + 16 * i) * ((2 * ntin + 3) & ~3);  // rows padded to 16 B
+#pragma unroll
+            for (int t = 0; t < 8; ++t) pv[i][t] = ldg4(pp + 4 * min(t, (ntin - 1) >> 1));  // 2 tiles per float4, clamped
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + sr + 16 * i;
+            float s = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (2 * t < ntin) { s += pv[i][t][0]; s2 += pv[i][t][1]; }
+                if (2 * t + 1 < ntin) { s += pv[i][t][2]; s2 += pv[i][t][3]; }
+            }
+            mean[i] = s * inv;
+            const float var = fmaxf(0.0f, s2 * inv - mean[i] * mean[i]);
+            rstd[i] = 1.0f / sqrtf(var + 1e-6f);
+            if (ln_wr && sc4 == 0) { stg(T.ln_stats + 2 * row, mean[i]); stg(T.ln_stats + 2 * row + 1, rstd[i]); }
+        }
+    }
+    f32x4 ra0[4], rb0[4], ra1[4], rb1[4];  // two register sets: a chunk's loads stay in flight across two compute phases
+    const float* __restrict__ Ag = T.A + (size_t)(row0 + sr) * T.lda + 4 * sc4;
+    const float* __restrict__ Bg = transb ? T.B + (size_t)(n0 + sr) * T.ldb + 4 * sc4 : T.B + (size_t)sr * T.ldb + n0 + 4 * sc4;
+    auto load_chunk = [&](f32x4 (&ra)[4], f32x4 (&rb)[4], int k0) {  // K is a multiple of 64: no guards, unconditional loads
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = ldg4(Ag + (size_t)(16 * i) * T.lda + k0);
+            rb[i] = transb ? ldg4(Bg + (size_t)(16 * i) * T.ldb + k0) : ldg4(Bg + (size_t)(k0 + 16 * i) * T.ldb);
+        }
+        if (a_ln) {
+            const int k = k0 + 4 * sc4;
+            const f32x4 g = ldg4(T.ln_g + k), be = ldg4(T.ln_b + k);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = (ra[i][e] - mean[i]) * rstd[i] * g[e] + be[e];
+                    ra[i][e] = (k + e < T.ln_width) ? v : 0.f;
+                }
+                if (ln_wr) stg4(T.ln_xout + (size_t)(row0 + sr + 16 * i) * T.lda + k, ra[i]);
+            }
+        }
+    };
+    auto store_chunk = [&](const f32x4 (&ra)[4], const f32x4 (&rb)[4], int buf) {
+        float* a = As + buf * 64 * G64_S;
+        float* b = Bs + buf * 64 * G64_S;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(a + (sr + 16 * i) * G64_S + 4 * sc4) = ra[i];
+            *reinterpret_cast<f32x4*>(b + (sr + 16 * i) * G64_S + 4 * sc4) = rb[i];
+        }
+    };
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float bias0 = (flags & GF_BIAS) ? ldg(T.bias + n0 + 32 * wc + c) : 0.f;
+    const float bias1 = (flags & GF_BIAS) ? ldg(T.bias + n0 + 32 * wc + 16 + c) : 0.f;
+
+    auto compute = [&](int buf) {
+        const float* a = As + buf * 64 * G64_S + (32 * wr + c) * G64_S + 4 * q;
+        const float* b = Bs + buf * 64 * G64_S;
+        f32x4 fa[2][2], fb[2][2];  // [pipeline slot][tile]: group g+1's fragments are read while group g multiplies
+        auto read_frags = [&](int slot, int g) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[slot][i] = *reinterpret_cast<const f32x4*>(a + 16 * i * G64_S + 16 * g);
+            if (transb) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[slot][j] = *reinterpret_cast<const f32x4*>(b + (32 * wc + 16 * j + c) * G64_S + 16 * g + 4 * q);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) fb[slot][j][s] = b[(16 * g + 4 * q + s) * G64_S + 32 * wc + 16 * j + c];
+            }
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) read_frags((g + 1) & 1, g + 1);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[g & 1][i][s], fb[g & 1][j][s], acc[i][j], 0, 0, 0);
+        }
+    };
+    // chunk ch computes from LDS slot ch & 1 while chunk ch+1 (set 0 / 1 alternating) and ch+2 are in flight
+    const int nchunks = K >> 6;
+    load_chunk(ra0, rb0, 0);
+    store_chunk(ra0, rb0, 0);
+    if (nchunks > 1) load_chunk(ra0, rb0, 64);
+    if (nchunks > 2) load_chunk(ra1, rb1, 128);
+    __syncthreads();
+#ifdef FQL_STAMPS  // diagnostic ablations (never in the product build): bit 15 = no streaming loads, bit 16 = no MFMAs
+    const bool dbg_noload = (flags >> 15) & 1, dbg_nocompute = (flags >> 16) & 1;
+#else
+    const bool dbg_noload = false, dbg_nocompute = false;
+#endif
+    for (int ch = 0; ch < nchunks; ch += 2) {
+        if (!dbg_nocompute) compute(0);
+        if (ch + 1 < nchunks) store_chunk(ra0, rb0, 1);
+        __syncthreads();
+        if (ch + 3 < nchunks && !dbg_noload) load_chunk(ra0, rb0, 64 * (ch + 3));
+        if (ch + 1 < nchunks) {
+            if (!dbg_nocompute) compute(1);
+            if (ch + 2 < nchunks) store_chunk(ra1, rb1, 0);
+            __syncthreads();
+            if (ch + 4 < nchunks && !dbg_noload) load_chunk(ra1, rb1, 64 * (ch + 4));
+        }
+    }
+
+    // ---- epilogue. C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
+    float s1[2][4], s2[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + 32 * wr + 16 * i + 4 * q + r;
+            s1[i][r] = 0.f; s2[i][r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + 32 * wc + 16 * j + c;
+                const size_t o = (size_t)row * T.ldc + n;
+                float v = acc[i][j][r] + (j ? bias1 : bias0);
+                if (flags & GF_SAVE_Z) stg(T.Zout + o, v);
+                if (flags & GF_GELU) v = gelu_f(v);
+                if (flags & GF_GELUGRAD) v *= gelu_grad_f(ldg(T.Zprev + o));
+                stg(T.C + o, v);
+                s1[i][r] += v; s2[i][r] += v * v;
+            }
+        }
+    }
+    if (flags & GF_LN_PART) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = s1[i][r], b = s2[i][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+                if (c == 0) {
+                    const int rl = 32 * wr + 16 * i + 4 * q + r;
+                    part[(wc * 64 + rl) * 2] = a;
+                    part[(wc * 64 + rl) * 2 + 1] = b;
+                }
+            }
+        __syncthreads();
+        if (tid < 64) {
+            float* pp = T.aux + (size_t)(row0 + tid) * ((2 * T.i1 + 3) & ~3) + 2 * tn;
+            stg(pp, part[tid * 2] + part[(64 + tid) * 2]);
+            stg(pp + 1, part[tid * 2 + 1] + part[(64 + tid) * 2 + 1]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(FQL_THREADS, 2) void fql_gemm64_kernel(const GemmTask* __restrict__ tasks, int ntasks) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int ti = find_task(tasks, ntasks, blockIdx.x);
+    const GemmTask& T = tasks[ti];
+    if (T.flags & GF_TRANS_B) gemm64_body<true>(T, lds);
+    else gemm64_body<false>(T, lds);
+}
+
+// ------------------------------------------------------------------------------------------------
 // K9 wgrad: dW[Kin, N] = X^T dZ (contraction over the batch), db[n] = sum_m dZ[m, n]
 //   implied by jax.grad, utils/flax_utils.py:137.
 // Workgroup tile 16 (Kin) x 64 (N).  The 4 waves split the batch (contraction) dimension, each holds
@@ -542,7 +750,7 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_wgrad_kernel(const WgradTask*
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void gelu_both(float x, float& g, float& dg) {
     const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    const float th = tanhf(u);
+    const float th = fast_tanh(u);
     const float du = 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
     g = 0.5f * x * (1.0f + th);
     dg = 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * du;
