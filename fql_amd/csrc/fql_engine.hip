@@ -91,7 +91,7 @@ struct Leaf {
 // ------------------------------------------------------------------------------------------------
 // program = ordered ops with read/write sets -> levels -> launches
 // ------------------------------------------------------------------------------------------------
-enum OpType { OP_GEMM, OP_GEMM64, OP_WGRAD, OP_LNBWD, OP_PREP, OP_POSTOS, OP_LOSS_CRITIC, OP_LOSS_Q, OP_LOSS_BC,
+enum OpType { OP_GEMM, OP_GEMM64, OP_WGRAD, OP_LNBWD, OP_PREP, OP_POSTOS, OP_EULER_FIN, OP_LOSS_CRITIC, OP_LOSS_Q, OP_LOSS_BC,
               OP_LOSS_ACTOR, OP_BEGIN, OP_ADAM, OP_FINALIZE };
 
 struct Op {
@@ -106,6 +106,7 @@ struct Op {
     LossQArgs lq;
     LossBcArgs lb;
     LossActorArgs la;
+    EulerFinishArgs ef;
     int fin_mode = 0;
     int level = 0;
     int lane = 0;            // 0 = critical lane (Euler chain, one-step backward), 1 = side lane
@@ -119,7 +120,7 @@ struct Launch {
     void* table = nullptr;  // device task table (GEMM/WGRAD/LNBWD)
     Op op;                  // arg-struct kernels
     int lane = 0;
-    bool tmt2 = false, kbig = false;
+    bool tmt2 = false, kbig = false, euler = false;
     std::vector<int> waits;      // launches of the OTHER lane that must have completed
     bool record_after = false;   // some launch of the other lane waits on this one
     hipEvent_t ev = nullptr;
@@ -182,6 +183,9 @@ struct fql_engine {
     int64_t* in_idx = nullptr;
     float *X_os = nullptr, *X_bc = nullptr, *X_eu = nullptr, *X_c1 = nullptr, *X_c2 = nullptr, *X_ct = nullptr;
     float *vel = nullptr, *w_rew = nullptr, *w_mask = nullptr, *w_act = nullptr, *tgt = nullptr;
+    float *X_e0 = nullptr, *C0 = nullptr, *Abuf[2] = {nullptr, nullptr}, *Vpart = nullptr;  // fused Euler chain
+    bool fused_euler = false;
+    int vp_tiles = 0;
     PassBuf p_os, p_os_bwd, p_bc, p_eu, p_c1[2], p_c2[2], p_ct[2];
     Program prog_fwdbwd, prog_opt, prog_loss;
     bool began = false;
@@ -473,6 +477,73 @@ struct fql_engine {
         }
     }
 
+    // Euler chain with 3 launches per step instead of 5 (agents/fql.py:155-171): [fold head partials -> a_s; layer 0 as a
+    // rank-(act+1) update of the loop-invariant C0 = obs W0 + b0; layer 1] , [middle layers] , [last hidden layer +
+    // head partials].  The head's reduction over hidden columns crosses workgroups, so each column tile publishes its
+    // 16 x ap partial and the consumer folds them in fixed order (deterministic).
+    void emit_euler_fused(Program& pr) {
+        const Net& n = nets[NET_BC];
+        const int nh = n.nl() - 1, fs = cfg.flow_steps;
+        const int od = cfg.obs_dim, ad = cfg.act_dim, ap = pad16(ad), inp_b = n.in_p();
+        const Layer& l0 = n.layers[0];
+        {
+            Op op{};
+            op.type = OP_GEMM;
+            GemmTask& t = op.gemm;
+            t.A = X_e0; t.lda = l0.in_p; t.B = P + l0.w; t.ldb = l0.out_p; t.bias = P + l0.b; t.C = C0; t.ldc = l0.out_p;
+            t.M = B; t.N = l0.out_p; t.K = l0.in_p; t.flags = GF_BIAS;
+            op.reads = {X_e0, t.B};
+            op.writes = {C0};
+            push(pr, op);
+        }
+        for (int s = 0; s < fs; ++s) {
+            for (int l = 1; l < nh; ++l) {
+                const Layer& ly = n.layers[l];
+                Op op{};
+                op.type = OP_GEMM;
+                GemmTask& t = op.gemm;
+                t.B = P + ly.w; t.ldb = ly.out_p; t.bias = P + ly.b;
+                t.M = B; t.N = ly.out_p; t.K = ly.in_p; t.ldc = ly.out_p;
+                t.flags = GF_BIAS | GF_GELU;
+                t.i1 = ap; t.i2 = ad; t.f0 = 1.0f / (float)fs; t.f1 = (float)s / (float)fs;
+                if (l == 1) {
+                    t.flags |= GF_A_EULER0;
+                    t.A = C0; t.lda = l0.out_p;
+                    t.ew = P + l0.w + (size_t)od * l0.out_p;
+                    if (s <= 1) { t.ea_in = X_eu + od; t.i0 = inp_b; } else { t.ea_in = Abuf[(s - 1) & 1]; t.i0 = ap; }
+                    op.reads = {C0, t.B, (s <= 1) ? (const void*)X_eu : (const void*)Abuf[(s - 1) & 1]};
+                    if (s >= 1) {
+                        t.evp = Vpart; t.eb = P + n.layers[nh].b; t.e_ntp = vp_tiles; t.ea_out = Abuf[s & 1];
+                        op.reads.push_back(Vpart);
+                        op.writes.push_back(Abuf[s & 1]);
+                    }
+                } else {
+                    t.A = p_eu.g[l - 1]; t.lda = ly.in_p;
+                    op.reads = {t.A, t.B};
+                }
+                if (l == nh - 1) {  // nh >= 3: never the same task as part 1
+                    t.flags |= GF_HEAD_PART;
+                    t.ew4 = P + n.layers[nh].w;
+                    t.evp = Vpart;
+                    t.C = nullptr;
+                    op.writes.push_back(Vpart);
+                } else {
+                    t.C = p_eu.g[l];
+                    op.writes.push_back(t.C);
+                }
+                push(pr, op);
+            }
+        }
+        Op op{};
+        op.type = OP_EULER_FIN;
+        const bool from_x = fs == 1;
+        op.ef = EulerFinishArgs{from_x ? X_eu + od : Abuf[(fs - 1) & 1], Vpart, P + n.layers[nh].b, tgt, B, ad, ap, vp_tiles,
+                                from_x ? inp_b : ap, 1.0f / (float)fs};
+        op.reads = {from_x ? (const void*)X_eu : (const void*)Abuf[(fs - 1) & 1], Vpart};
+        op.writes = {tgt};
+        push(pr, op);
+    }
+
     // backward of one pass: dz[L] must already hold dLoss/dOut.  rows: view [row_off, row_off+M) of a
     // taller forward pass (one-step actor: only the (obs, z) block is differentiated).
     void emit_backward(Program& pr, const PassBuf& p, int row_off, int M, bool param_grads, bool input_grad) {
@@ -630,7 +701,8 @@ struct fql_engine {
                         tile += (t.M / (16 * t.tmt)) * t.ntn;
                         if (t.tmt == 2) L.tmt2 = true;
                         if (t.K > 512) L.kbig = true;
-                        L.lds = std::max(L.lds, ((size_t)16 * t.tmt * (t.K + 4) + 1024 * t.tmt) * sizeof(float));
+                        if (t.flags & (GF_A_EULER0 | GF_HEAD_PART)) L.euler = true;
+                        L.lds = std::max(L.lds, ((size_t)16 * t.tmt * (t.K + 4) + 1024 * t.tmt + 1280) * sizeof(float));
                         tb.push_back(t);
                     }
                     L.table = dalloc(owner, tb.size() * sizeof(GemmTask) / sizeof(float) + 4);
@@ -719,7 +791,9 @@ struct fql_engine {
                 for (int w : L.waits) if (pr.launches[w].ev) HIP_CHECK(hipStreamWaitEvent(s, pr.launches[w].ev, 0));
             switch (L.type) {
                 case OP_GEMM:
-                    if (L.tmt2 && L.kbig) hipLaunchKernelGGL((fql_gemm16_kernel<true, true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
+                    if (L.euler && L.kbig) hipLaunchKernelGGL((fql_gemm16_euler_kernel<true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
+                    else if (L.euler) hipLaunchKernelGGL((fql_gemm16_euler_kernel<false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
+                    else if (L.tmt2 && L.kbig) hipLaunchKernelGGL((fql_gemm16_kernel<true, true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
                     else if (L.tmt2) hipLaunchKernelGGL((fql_gemm16_kernel<true, false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
                     else if (L.kbig) hipLaunchKernelGGL((fql_gemm16_kernel<false, true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
                     else hipLaunchKernelGGL((fql_gemm16_kernel<false, false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
@@ -738,6 +812,9 @@ struct fql_engine {
                     break;
                 case OP_POSTOS:
                     hipLaunchKernelGGL(fql_post_onestep_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.postos);
+                    break;
+                case OP_EULER_FIN:
+                    hipLaunchKernelGGL(fql_euler_finish_kernel, dim3((L.op.ef.M * L.op.ef.ad + FQL_THREADS - 1) / FQL_THREADS), dim3(FQL_THREADS), 0, s, L.op.ef);
                     break;
                 case OP_LOSS_CRITIC:
                     hipLaunchKernelGGL(fql_loss_critic_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.lc);
@@ -820,8 +897,10 @@ struct fql_engine {
         {   // batch gather + noise + every network input
             Op op{};
             op.type = OP_PREP;
-            op.prep = PrepArgs{d_src, st, seed, B, od, ad, inp_c, inp_b, ap, X_os, X_bc, X_eu, X_c1, X_c2, X_ct, vel, w_rew, w_mask, w_act};
+            op.prep = PrepArgs{d_src, st, seed, B, od, ad, inp_c, inp_b, ap, X_os, X_bc, X_eu, X_c1, X_c2, X_ct, vel, w_rew, w_mask, w_act,
+                               fused_euler ? X_e0 : nullptr};
             op.writes = {X_os, X_bc, X_eu, X_c1, X_c2, X_ct, vel, w_rew, w_mask, w_act};
+            if (fused_euler) op.writes.push_back(X_e0);
             push(pr, op);
         }
         place("os", 1, true);
@@ -885,6 +964,8 @@ struct fql_engine {
         // Euler chain through the BC flow (fql.py:155-171): flow_steps sequential forwards
         place("eu", 0, false);
         const int fs = cfg.flow_steps;
+        if (fused_euler) emit_euler_fused(pr);
+        else
         for (int s = 0; s < fs; ++s)
             emit_forward(pr, p_eu, false, GF_EULER | (s == fs - 1 ? GF_EULER_LAST : 0), X_eu, tgt, 1.0f / (float)fs,
                          (float)(s + 1) / (float)fs);
@@ -968,6 +1049,19 @@ struct fql_engine {
         const int ap = pad16(ad);
         vel = dalloc(W, (size_t)B * ap); w_act = dalloc(W, (size_t)B * ap); tgt = dalloc(W, (size_t)B * ap);
         w_rew = dalloc(W, B); w_mask = dalloc(W, B);
+        {   // fused Euler chain (layers 0+1 and last-hidden+head per launch): plain actor MLPs with >= 2 hidden layers
+            const Net& nb = nets[NET_BC];
+            const int nh = nb.nl() - 1;
+            fused_euler = getenv("FQL_NO_FUSED_EULER") == nullptr && !cfg.actor_layer_norm && ad <= 16 && nh >= 3;
+            if (fused_euler) {
+                X_e0 = dalloc(W, (size_t)B * inp_b);
+                C0 = dalloc(W, (size_t)B * nb.layers[0].out_p);
+                Abuf[0] = dalloc(W, (size_t)B * ap); Abuf[1] = dalloc(W, (size_t)B * ap);
+                vp_tiles = (nb.layers[nh - 1].out_p / 16 + 1) / 2;
+                if (vp_tiles > 32) fused_euler = false;
+                Vpart = dalloc(W, (size_t)std::max(vp_tiles, 1) * B * ap);
+            }
+        }
         p_os = make_pass(W, NET_OS, 3 * B, X_os, false, false);
         {   // backward view of the (obs, z) block: own gradient buffers, forward buffers shared with p_os
             p_os_bwd = p_os;

@@ -37,6 +37,8 @@ enum : int {
     GF_EULER = 1 << 7,      // epilogue: a += v / flow_steps, t column := t_next    agents/fql.py:166-169
     GF_EULER_LAST = 1 << 8, // ... and store clip(a, -1, 1) as the distillation target  agents/fql.py:170
     GF_CLIP_OUT = 1 << 9,   // epilogue: C = clip(acc + bias, -1, 1)            agents/fql.py:152
+    GF_A_EULER0 = 1 << 11,  // fused Euler step, part 1: A tile = GELU(C0 + a W0[act rows] + t W0[t row]) built in LDS
+    GF_HEAD_PART = 1 << 12, // fused Euler step, part 3: epilogue multiplies the GELU tile into the action head (partials)
     GF_LN_PART = 1 << 10,   // gemm64 epilogue: per-row (sum, sum sq) of this 64-column tile -> aux[row][i1 tiles][2]
 };
 
@@ -62,7 +64,15 @@ struct GemmTask {
     int wk;             // K-split ways among the 4 waves (1, 2 or 4); column tiles per workgroup = 4 / wk
     int tmt;            // 16-row tiles per workgroup (1 or 2)
     int i0, i1, i2;     // GF_EULER: ld of aux, column offset of the action block, act_dim
-    float f0, f1;       // GF_EULER: 1/flow_steps, t_next
+    float f0, f1;       // GF_EULER: 1/flow_steps, t_next;  GF_A_EULER0: 1/flow_steps, t of this step
+    // fused Euler step (agents/fql.py:166-169 with layers 0+1 and last-hidden+head each in one launch)
+    const float* ea_in;  // [M, i0] current actions a_s (row stride i0)
+    float* ea_out;       // [M, ap] a_s as used by this step (written by column tile 0) or null
+    const float* ew;     // A_EULER0: W0 rows of the action block and t, [ad+1][K]
+    const float* ew4;    // HEAD_PART: head kernel [N][ap]
+    float* evp;          // head partials [ntiles][M][ap]: read by A_EULER0 (null on step 0), written by HEAD_PART
+    const float* eb;     // head bias [ap]
+    int e_ntp;           // number of partial tiles to fold (A_EULER0)
 };
 
 struct WgradTask {
@@ -275,7 +285,7 @@ __device__ __forceinline__ void gemm_wave(f32x4 (&acc)[TMT], const BAddr& ba, co
 
 // NA = float4 loads per thread that cover 16 rows of the A tile (16 * K / 4 <= NA * 256);
 // TMT = 16-row tiles per workgroup (1: latency lane, 2: throughput lane).
-template <int NA, int TMT>
+template <int NA, int TMT, bool EUL>
 __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
     const int local = blockIdx.x - T.tile0;
     const int tm = local / T.ntn, tn = local - tm * T.ntn;
@@ -311,6 +321,92 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
     float b0[32], b1[32];
     BAddr ba = transb ? gemm_baddr<true>(T, n0, c, q) : gemm_baddr<false>(T, n0, c, q);
     float bias = 0.f;
+    float* ea = red + 1024 * TMT;  // [16][32] fused Euler: actions of this step
+    float* hs = ea + 512;          // [16][36] fused Euler: last hidden tile feeding the head partial
+    const bool euler0 = EUL && TMT == 1 && (flags & GF_A_EULER0);
+    const bool head = EUL && TMT == 1 && (flags & GF_HEAD_PART);
+    auto issue_b = [&]() {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { b0[i] = 0.f; b1[i] = 0.f; }  // defined on every path: stay in VGPRs
+        if (active) {
+            const int nfull = (gend - gbeg) >> 3;
+            if (transb) {
+                if (nfull > 0) gemm_load_chunk<true>(b0, ba.base + (size_t)(16 * gbeg) * ba.kstep, ba.ldb);
+                if (nfull > 1) gemm_load_chunk<true>(b1, ba.base + (size_t)(16 * (gbeg + 8)) * ba.kstep, ba.ldb);
+            } else {
+                if (nfull > 0) gemm_load_chunk<false>(b0, ba.base + (size_t)(16 * gbeg) * ba.kstep, ba.ldb);
+                if (nfull > 1) gemm_load_chunk<false>(b1, ba.base + (size_t)(16 * (gbeg + 8)) * ba.kstep, ba.ldb);
+            }
+            if ((flags & GF_BIAS) && kp == 0) bias = ldg(T.bias + n0 + c);
+        }
+    };
+    float bw4[8];  // head-kernel fragments of this workgroup's 32 hidden columns (wave 0 only)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bw4[i] = 0.f;
+    if (head && wave == 0) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int k = tn * 32 + 16 * g + 4 * q + s4;
+                const float v = ldg(T.ew4 + (size_t)min(k, N - 1) * T.i1 + c);
+                bw4[4 * g + s4] = (k < N) ? v : 0.f;
+            }
+    }
+    if (euler0) {
+        // layers 0 and 1 of the velocity field in one launch: the obs part of layer 0 (C0 = obs W0 + b0) is loop
+        // invariant over the Euler steps, only the rank-(act+1) update with (a_s, t_s) changes.
+        issue_b();
+        const int ad = T.i2, apw = T.i1, M = T.M;
+        // layer 0 as MFMA: [16 x 16] (a_s | t_s | 0) times the 16 rows of W0 that start at the action block (rows past
+        // the t row are zero padding of the arena), accumulated onto C0.  Wave w owns column tiles w, w+4, ...
+        // C0 / W0 fragment loads do not depend on a_s: issue them before folding the head partials.
+        constexpr int CT = NA;      // column tiles per wave: K / 64 <= NA (NA covers 16 * K / 4 float4 over 256 threads)
+        f32x4 cacc[CT];
+        float wf[CT][4];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int ct = min(wave + 4 * t, (K >> 4) - 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cacc[t][i] = ldg(T.A + (size_t)(row0 + 4 * q + i) * T.lda + 16 * ct + c);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) wf[t][s4] = ldg(T.ew + (size_t)(4 * q + s4) * K + 16 * ct + c);
+        }
+        for (int e = tid; e < 16 * 16; e += FQL_THREADS) {
+            const int r = e >> 4, j = e & 15;
+            float a = 0.f;
+            if (j < ad) {
+                a = ldg(T.ea_in + (size_t)(row0 + r) * T.i0 + j);
+                if (T.evp) {  // a_s = a_{s-1} + (sum of head partials + head bias) / flow_steps, fixed summation order
+                    float pv[32];
+#pragma unroll
+                    for (int tp = 0; tp < 32; ++tp) pv[tp] = ldg(T.evp + ((size_t)min(tp, T.e_ntp - 1) * M + row0 + r) * apw + j);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int tp = 0; tp < 32; ++tp) sum += (tp < T.e_ntp) ? pv[tp] : 0.f;
+                    a += (sum + ldg(T.eb + j)) * T.f0;
+                }
+                if (tn == 0 && T.ea_out) stg(T.ea_out + (size_t)(row0 + r) * apw + j, a);
+            } else if (j == ad) {
+                a = T.f1;  // t_s
+            }
+            ea[r * 32 + j] = a;
+        }
+        __syncthreads();
+        {
+            const f32x4 af = *reinterpret_cast<const f32x4*>(&ea[c * 32 + 4 * q]);  // A'[row c][k = 4 q + s]
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                if (wave + 4 * t < (K >> 4)) {
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) cacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s4], wf[t][s4], cacc[t], 0, 0, 0);
+                    const int ct = wave + 4 * t;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) lds[(4 * q + i) * S + 16 * ct + c] = gelu_f(cacc[t][i]);
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int pass = 0; pass < TMT; ++pass) {
         f32x4 av[NA];
@@ -321,21 +417,7 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
             const int r = f / k4, kk = f - r * k4;
             av[i] = ldg4(Ag + (size_t)r * T.lda + 4 * kk);
         }
-        if (pass == 0) {
-#pragma unroll
-            for (int i = 0; i < 32; ++i) { b0[i] = 0.f; b1[i] = 0.f; }  // defined on every path: stay in VGPRs
-            if (active) {
-                const int nfull = (gend - gbeg) >> 3;
-                if (transb) {
-                    if (nfull > 0) gemm_load_chunk<true>(b0, ba.base + (size_t)(16 * gbeg) * ba.kstep, ba.ldb);
-                    if (nfull > 1) gemm_load_chunk<true>(b1, ba.base + (size_t)(16 * (gbeg + 8)) * ba.kstep, ba.ldb);
-                } else {
-                    if (nfull > 0) gemm_load_chunk<false>(b0, ba.base + (size_t)(16 * gbeg) * ba.kstep, ba.ldb);
-                    if (nfull > 1) gemm_load_chunk<false>(b1, ba.base + (size_t)(16 * (gbeg + 8)) * ba.kstep, ba.ldb);
-                }
-                if ((flags & GF_BIAS) && kp == 0) bias = ldg(T.bias + n0 + c);
-            }
-        }
+        if (pass == 0) issue_b();
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int f = tid + i * FQL_THREADS;
@@ -344,6 +426,7 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
                 *reinterpret_cast<f32x4*>(&lds[(16 * pass + r) * S + 4 * kk]) = av[i];
             }
         }
+    }
     }
     STAMP();
     __syncthreads();
@@ -398,11 +481,35 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
             for (int r = 0; r < TMT; ++r) *reinterpret_cast<f32x4*>(&red[((((kp - 1) * NW + nt) * TMT + r) * 64 + lane) * 4]) = acc[r];
         }
         __syncthreads();
-        if (kp > 0) return;
+        if (kp > 0 && !head) return;
+        if (kp == 0)
         for (int p = 1; p < WK; ++p) {
 #pragma unroll
             for (int r = 0; r < TMT; ++r) acc[r] += *reinterpret_cast<const f32x4*>(&red[((((p - 1) * NW + nt) * TMT + r) * 64 + lane) * 4]);
         }
+    }
+    if (head) {
+        // last hidden layer + action head in one launch: this workgroup's 16 x 32 GELU tile is multiplied into its 32
+        // rows of the head kernel; the 16 x ap partial goes to evp[tn] and is folded by the next step's first launch.
+        if (kp == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hs[(4 * q + i) * 36 + 16 * nt + c] = active ? gelu_f(acc[0][i] + bias) : 0.f;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            f32x4 pa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(&hs[c * 36 + 16 * g + 4 * q]);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) pa = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s4], bw4[4 * g + s4], pa, 0, 0, 0);
+            }
+            if (c < T.i1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) stg(T.evp + ((size_t)tn * T.M + row0 + 4 * q + i) * T.i1 + c, pa[i]);
+            }
+        }
+        return;
     }
     if (!active) return;
     STAMP();
@@ -454,14 +561,24 @@ __global__ __launch_bounds__(FQL_THREADS, FQL_GEMM_WAVES) void fql_gemm16_kernel
     const int ti = find_task(tasks, ntasks, blockIdx.x);
     const GemmTask& T = tasks[ti];
     if (TMT2 && T.tmt == 2) {
-        if (T.K <= 128) gemm16_body<2, 2>(T, lds);
-        else if (!KBIG || T.K <= 512) gemm16_body<8, 2>(T, lds);
-        else gemm16_body<16, 2>(T, lds);
+        if (T.K <= 128) gemm16_body<2, 2, false>(T, lds);
+        else if (!KBIG || T.K <= 512) gemm16_body<8, 2, false>(T, lds);
+        else gemm16_body<16, 2, false>(T, lds);
     } else {
-        if (T.K <= 128) gemm16_body<2, 1>(T, lds);
-        else if (!KBIG || T.K <= 512) gemm16_body<8, 1>(T, lds);
-        else gemm16_body<16, 1>(T, lds);
+        if (T.K <= 128) gemm16_body<2, 1, false>(T, lds);
+        else if (!KBIG || T.K <= 512) gemm16_body<8, 1, false>(T, lds);
+        else gemm16_body<16, 1, false>(T, lds);
     }
+}
+// Euler-chain launches (fused layer-0 build / head partial): own kernel so their registers do not tax the others
+template <bool KBIG>
+__global__ __launch_bounds__(FQL_THREADS) void fql_gemm16_euler_kernel(const GemmTask* __restrict__ tasks, int ntasks) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int ti = find_task(tasks, ntasks, blockIdx.x);
+    const GemmTask& T = tasks[ti];
+    if (T.K <= 128) gemm16_body<2, 1, true>(T, lds);
+    else if (!KBIG || T.K <= 512) gemm16_body<8, 1, true>(T, lds);
+    else gemm16_body<16, 1, true>(T, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -852,6 +969,7 @@ struct PrepArgs {
     int inp_c, inp_b;  // padded input widths: critic/onestep (od+ad), bc_flow (od+ad+1)
     int ap;            // padded action width (ld of the [B, ap] action-shaped buffers)
     float *X_os, *X_bc, *X_eu, *X_c1, *X_c2, *X_ct, *vel, *w_rew, *w_mask, *w_act;
+    float* X_e0;  // [B, inp_b] observations only (fused Euler chain: loop-invariant part of layer 0) or null
 };
 
 // agents/fql.py:52-56 (x_t, vel), :144-150 (noise), utils/datasets.py:64-100 (index draw + gather),
@@ -897,6 +1015,7 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_prep_kernel(PrepArgs P) {
             const float xt = (1.0f - tt) * xx + tt * av;             // fql.py:55
             P.X_bc[(size_t)b * w + j] = is_obs ? o : (is_act ? xt : (j == od + ad ? tt : 0.f));
             P.X_eu[(size_t)b * w + j] = is_obs ? o : (is_act ? zz : 0.f);  // t_0 = 0
+            if (P.X_e0) P.X_e0[(size_t)b * w + j] = is_obs ? o : 0.f;
         }
         if (is_act) {
             P.vel[(size_t)b * P.ap + a] = av - xx;                     // fql.py:56
@@ -1175,6 +1294,28 @@ __global__ void fql_finalize_kernel(DevState* st, int nleaves, int do_grad_stats
             st->rng_step += 1;
         }
     }
+}
+
+// fused Euler chain, last step: target = clip(a_{n-1} + (sum of head partials + bias) / flow_steps)  (agents/fql.py:169-170)
+struct EulerFinishArgs {
+    const float* a_in;   // [M, ap]
+    const float* evp;    // [ntp][M][ap]
+    const float* eb;     // [ap]
+    float* tgt;          // [M, ap]
+    int M, ad, ap, ntp, a_ld;
+    float scale;
+};
+__global__ __launch_bounds__(FQL_THREADS) void fql_euler_finish_kernel(EulerFinishArgs P) {
+    const int e = blockIdx.x * FQL_THREADS + threadIdx.x;
+    if (e >= P.M * P.ad) return;
+    const int r = e / P.ad, j = e - r * P.ad;
+    float pv[32];
+#pragma unroll
+    for (int tp = 0; tp < 32; ++tp) pv[tp] = ldg(P.evp + ((size_t)min(tp, P.ntp - 1) * P.M + r) * P.ap + j);
+    float sum = 0.f;
+#pragma unroll
+    for (int tp = 0; tp < 32; ++tp) sum += (tp < P.ntp) ? pv[tp] : 0.f;
+    stg(P.tgt + (size_t)r * P.ap + j, clip1(ldg(P.a_in + (size_t)r * P.a_ld + j) + (sum + ldg(P.eb + j)) * P.scale));
 }
 
 // sample_actions / flow_actions input assembly: X[n_pad, inp] = concat(obs, noise[, t=0])

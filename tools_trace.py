@@ -6,7 +6,7 @@ import sys
 
 path = sys.argv[1]
 files = glob.glob(path + '/**/*kernel_trace.csv', recursive=True)
-rows = [r for r in csv.DictReader(open(files[0])) if r['Kernel_Name'].startswith('fql_')]
+rows = [r for r in csv.DictReader(open(files[0])) if 'fql_' in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'prep' in r['Kernel_Name']]
 s = rows[idx[-2]:idx[-1]]
@@ -16,7 +16,7 @@ end = t0
 for r in s:
     st, en = int(r['Start_Timestamp']), int(r['End_Timestamp'])
     end = max(end, en)
-    name = r['Kernel_Name'].split('(')[0]
+    name = r['Kernel_Name'].split('(')[0].replace('void ', '')
     if '-v' in sys.argv:
         print(f"q{r['Queue_Id']:>2s} {name[:24]:24s} grid={int(r['Grid_Size_X'])//max(1,int(r['Workgroup_Size_X'])):5d} start={(st-t0)/1e3:8.1f} end={(en-t0)/1e3:8.1f} dur={(en-st)/1e3:6.1f}")
     a = agg.setdefault(name, [0, 0.0])
