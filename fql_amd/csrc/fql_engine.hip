@@ -471,6 +471,12 @@ struct fql_engine {
                     if (aux2) op.writes.push_back(aux2);
                 } else {
                     op.writes.push_back(t.C);
+                    if (final_flags & GF_OS_SCATTER) {
+                        t.aux = aux; t.aux2 = aux2;
+                        t.i0 = nets[NET_C0].in_p(); t.i1 = cfg.obs_dim; t.i2 = cfg.act_dim;
+                        op.writes.push_back(aux);
+                        op.writes.push_back(aux2);
+                    }
                 }
             }
             push(pr, op);
@@ -546,7 +552,9 @@ struct fql_engine {
 
     // backward of one pass: dz[L] must already hold dLoss/dOut.  rows: view [row_off, row_off+M) of a
     // taller forward pass (one-step actor: only the (obs, z) block is differentiated).
-    void emit_backward(Program& pr, const PassBuf& p, int row_off, int M, bool param_grads, bool input_grad) {
+    void emit_backward(Program& pr, const PassBuf& p, int row_off, int M, bool param_grads, bool input_grad,
+                       const void* align_with = nullptr) {
+        size_t first_op = pr.ops.size();
         const Net& n = nets[p.net];
         const int L = n.nl() - 1;
         auto rows = [&](float* base, int ld) { return base + (size_t)row_off * ld; };
@@ -574,6 +582,27 @@ struct fql_engine {
                 emit_lane = keep;
             }
             if (l == 0 && !input_grad) break;
+            if (l == L && l > 0 && ly.out == 1 && n.layers[l - 1].ln) {
+                // scalar head behind a LayerNorm (critic Q): dY = dq (x) w is rank 1, synthesised inside the LN-backward
+                const Layer& prev = n.layers[l - 1];
+                Op lo{};
+                lo.type = OP_LNBWD;
+                LnBwdTask& q = lo.ln;
+                q.dY = nullptr;
+                q.dq = dz; q.ldq = ly.out_p; q.wq = P + ly.w; q.ldw = ly.out_p;
+                q.Z = rows(p.z[l - 1], prev.out_p);
+                q.stats = p.stats[l - 1] + (size_t)row_off * 2;
+                q.gamma = P + prev.g;
+                q.dZ = p.dz[l - 1];
+                q.dgamma = param_grads ? G + prev.g : nullptr;
+                q.dbeta = param_grads ? G + prev.be : nullptr;
+                q.M = M; q.H = prev.out_p; q.ld = prev.out_p; q.width = prev.out;
+                lo.reads = {dz, p.z[l - 1], p.stats[l - 1], q.gamma};
+                lo.writes = {q.dZ};
+                if (param_grads) { lo.writes.push_back(q.dgamma); lo.writes.push_back(q.dbeta); }
+                push(pr, lo);
+                continue;
+            }
             // dgrad: dX = dZ W^T
             Op op{};
             op.type = OP_GEMM;
@@ -621,6 +650,10 @@ struct fql_engine {
                 push(pr, op);
             }
         }
+        // level alignment: start this chain together with a sibling chain so their per-level tasks share launches
+        if (align_with)
+            for (size_t i = first_op; i < pr.ops.size(); ++i)
+                if (pr.ops[i].type != OP_WGRAD) { pr.ops[i].reads.push_back(align_with); break; }
     }
 
     // ---------------------------------------------------------------------------------------
@@ -747,6 +780,18 @@ struct fql_engine {
                 pr.launches.push_back(L);
             }
           }
+        }
+        if (getenv("FQL_DUMP")) {
+            int cnt[FQL_LANES] = {};
+            for (const Launch& L : pr.launches) {
+                cnt[L.lane]++;
+                int lv = -1;
+                for (int oi = 0; oi < (int)pr.ops.size(); ++oi) if (launch_of[oi] == (int)(&L - pr.launches.data())) lv = pr.ops[oi].level;
+                fprintf(stderr, "[fql] level %3d lane %d type %2d ntasks %2d grid %5d\n", lv, L.lane, (int)L.type, L.ntasks, L.grid);
+            }
+            fprintf(stderr, "[fql] launches per lane:");
+            for (int l = 0; l < FQL_LANES; ++l) fprintf(stderr, " %d", cnt[l]);
+            fprintf(stderr, "\n");
         }
         // cross-lane edges: a launch waits for the latest launch of the other lane it depends on (lane streams
         // are in-order, so that covers the earlier ones); skip waits already implied by an earlier wait.
@@ -905,13 +950,13 @@ struct fql_engine {
         }
         place("os", 1, true);
         // one-step actor on [next_obs|eps1 ; obs|z ; obs|eps2]  (agents/fql.py:25,65,82)
-        emit_forward(pr, p_os, with_grads);
-        {
+        emit_forward(pr, p_os, with_grads, GF_OS_SCATTER, X_ct, X_c2);
+        {   // mse metric only (agents/fql.py:82-83); the clipped actions were scattered by the head's epilogue
             Op op{};
             op.type = OP_POSTOS;
             op.postos = PostOsArgs{p_os.out, w_act, X_ct, X_c2, st, B, od, ad, inp_c, ap};
             op.reads = {p_os.out, w_act};
-            op.writes = {X_ct, X_c2, I_MSE};
+            op.writes = {I_MSE};
             push(pr, op);
         }
         place("c1", 1, true);
@@ -952,15 +997,18 @@ struct fql_engine {
         {
             Op op{};
             op.type = OP_LOSS_Q;
-            op.lq = LossQArgs{p_c2[0].out, p_c2[1].out, with_grads ? p_c2[0].dz.back() : nullptr,
-                              with_grads ? p_c2[1].dz.back() : nullptr, st, B, cfg.normalize_q_loss, with_grads ? 1 : 0};
+            // without normalize_q_loss dQ = -1/(2B) is a constant (filled once at workspace build): the input-gradient
+            // chain through the critic then does not wait for the Q heads or this kernel
+            const bool dyn_dq = with_grads && cfg.normalize_q_loss;
+            op.lq = LossQArgs{p_c2[0].out, p_c2[1].out, dyn_dq ? p_c2[0].dz.back() : nullptr,
+                              dyn_dq ? p_c2[1].dz.back() : nullptr, st, B, cfg.normalize_q_loss, dyn_dq ? 1 : 0};
             op.reads = {p_c2[0].out, p_c2[1].out};
             op.writes = {I_Q};
-            if (with_grads) { op.writes.push_back(p_c2[0].dz.back()); op.writes.push_back(p_c2[1].dz.back()); }
+            if (dyn_dq) { op.writes.push_back(p_c2[0].dz.back()); op.writes.push_back(p_c2[1].dz.back()); }
             push(pr, op);
         }
         if (with_grads)
-            for (int e = 0; e < 2; ++e) emit_backward(pr, p_c2[e], 0, B, false, true);
+            for (int e = 0; e < 2; ++e) emit_backward(pr, p_c2[e], 0, B, false, true, I_CR);  // in phase with the c1 chain
         // Euler chain through the BC flow (fql.py:155-171): flow_steps sequential forwards
         place("eu", 0, false);
         const int fs = cfg.flow_steps;
@@ -1076,6 +1124,11 @@ struct fql_engine {
             p_c1[e] = make_pass(W, NET_C0 + e, B, X_c1, true, false);
             p_c2[e] = make_pass(W, NET_C0 + e, B, X_c2, true, true);
             p_ct[e] = make_pass(W, NET_T0 + e, B, X_ct, false, false);
+        }
+        if (!cfg.normalize_q_loss) {
+            std::vector<float> h((size_t)B * 16, 0.f);
+            for (int b = 0; b < B; ++b) h[(size_t)b * 16] = -1.0f / (2.0f * (float)B);
+            for (int e = 0; e < 2; ++e) HIP_CHECK(hipMemcpy(p_c2[e].dz.back(), h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
         }
         build_step_program(prog_fwdbwd, true);
         build_opt_program(prog_opt);

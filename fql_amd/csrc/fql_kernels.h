@@ -39,6 +39,7 @@ enum : int {
     GF_CLIP_OUT = 1 << 9,   // epilogue: C = clip(acc + bias, -1, 1)            agents/fql.py:152
     GF_A_EULER0 = 1 << 11,  // fused Euler step, part 1: A tile = GELU(C0 + a W0[act rows] + t W0[t row]) built in LDS
     GF_HEAD_PART = 1 << 12, // fused Euler step, part 3: epilogue multiplies the GELU tile into the action head (partials)
+    GF_OS_SCATTER = 1 << 13, // one-step head on [next_obs; obs; obs] rows: also write clip(out) into the critic inputs
     GF_LN_PART = 1 << 10,   // gemm64 epilogue: per-row (sum, sum sq) of this 64-column tile -> aux[row][i1 tiles][2]
 };
 
@@ -95,6 +96,10 @@ struct LnBwdTask {
     float* dbeta;        // [H] or null
     int M, H, ld, width;
     int tile0, ntiles_rows; // row tasks first, then column-sum tiles
+    // scalar head (critic Q): dY[m][k] = dq[m * ldq] * wq[k * ldw] is a rank-1 product, no dgrad GEMM needed
+    const float* dq;
+    const float* wq;
+    int ldq, ldw;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -539,6 +544,12 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
         if (flags & GF_GELUGRAD) v *= gelu_grad_f(ldg(T.Zprev + o));
         if (flags & GF_CLIP_OUT) v = clip1(v);
         stg(T.C + o, v);
+        if ((flags & GF_OS_SCATTER) && n < T.i2) {
+            // agents/fql.py:26 next_actions = clip(onestep(next_obs)) -> target-critic input; :69 clip(actor_actions) -> critic input
+            const int B3 = T.M / 3;
+            if (row < B3) stg(T.aux + (size_t)row * T.i0 + T.i1 + n, clip1(v));
+            else if (row < 2 * B3) stg(T.aux2 + (size_t)(row - B3) * T.i0 + T.i1 + n, clip1(v));
+        }
     }
     }
 #ifdef FQL_STAMPS
@@ -872,31 +883,35 @@ __device__ __forceinline__ void gelu_both(float x, float& g, float& dg) {
     g = 0.5f * x * (1.0f + th);
     dg = 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * du;
 }
-__global__ __launch_bounds__(FQL_THREADS) void fql_lnbwd_kernel(const LnBwdTask* __restrict__ tasks, int ntasks) {
-    __shared__ float red[2][16][16];
-    const int ti = find_task(tasks, ntasks, blockIdx.x);
-    const LnBwdTask& T = tasks[ti];
+template <bool SYN>  // SYN: dY[m][k] = dq[m] * wq[k] (scalar head), else dY is read from memory
+__device__ __forceinline__ void lnbwd_body(const LnBwdTask& T, float (*red)[16][16]) {
     const int local = blockIdx.x - T.tile0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (local < T.ntiles_rows) {
         const int row = local * 4 + wave;
         if (row >= T.M) return;
-        const float mean = T.stats[2 * row], rstd = T.stats[2 * row + 1];
+        const float mean = ldg(T.stats + 2 * row), rstd = ldg(T.stats + 2 * row + 1);
         const float* dy = T.dY + (size_t)row * T.ld;
         const float* z = T.Z + (size_t)row * T.ld;
-        float d[16], xh[16], dg[16];  // H <= 1024: <= 16 elements per lane, k = lane + 64 i
+        const float dqr = SYN ? ldg(T.dq + (size_t)row * T.ldq) : 0.f;
+        float zz[16], dd[16], gm[16];  // H <= 1024: <= 16 elements per lane, k = lane + 64 i; all loads issued first
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int k = min(lane + 64 * i, T.H - 1);
+            zz[i] = ldg(z + k);
+            dd[i] = SYN ? dqr * ldg(T.wq + (size_t)k * T.ldw) : ldg(dy + k);
+            gm[i] = ldg(T.gamma + k);
+        }
+        float d[16], xh[16], dg[16];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int k = lane + 64 * i;
-            d[i] = 0.f; xh[i] = 0.f; dg[i] = 0.f;
-            if (k < T.width) {
-                float g;
-                gelu_both(z[k], g, dg[i]);
-                xh[i] = (g - mean) * rstd;
-                d[i] = dy[k] * T.gamma[k];
-                s1 += d[i]; s2 += d[i] * xh[i];
-            }
+            float g;
+            gelu_both(zz[i], g, dg[i]);
+            xh[i] = (g - mean) * rstd;
+            d[i] = dd[i] * gm[i];
+            if (k < T.width) { s1 += d[i]; s2 += d[i] * xh[i]; }
         }
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -909,19 +924,30 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_lnbwd_kernel(const LnBwdTask*
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int k = lane + 64 * i;
-            if (k < T.H) dz[k] = (k < T.width) ? rstd * (d[i] - m1 - xh[i] * m2) * dg[i] : 0.f;
+            if (k < T.H) stg(dz + k, (k < T.width) ? rstd * (d[i] - m1 - xh[i] * m2) * dg[i] : 0.f);
         }
     } else {
         const int cc = threadIdx.x & 15, rg = threadIdx.x >> 4;
         const int col = (local - T.ntiles_rows) * 16 + cc;
         float sg = 0.f, sb = 0.f;
         if (col < T.width) {
-#pragma unroll 4
-            for (int m = rg; m < T.M; m += 16) {
-                const float mean = T.stats[2 * m], rstd = T.stats[2 * m + 1];
-                const float dd = T.dY[(size_t)m * T.ld + col];
-                const float xh = (gelu_f(T.Z[(size_t)m * T.ld + col]) - mean) * rstd;
-                sg += dd * xh; sb += dd;
+            const float wc = SYN ? ldg(T.wq + (size_t)col * T.ldw) : 0.f;
+            for (int m0 = rg; m0 < T.M; m0 += 64) {  // 4 rows per thread in flight
+                float mn[4], rs[4], dv[4], zv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int m = min(m0 + 16 * u, T.M - 1);
+                    mn[u] = ldg(T.stats + 2 * m); rs[u] = ldg(T.stats + 2 * m + 1);
+                    dv[u] = SYN ? ldg(T.dq + (size_t)m * T.ldq) * wc : ldg(T.dY + (size_t)m * T.ld + col);
+                    zv[u] = ldg(T.Z + (size_t)m * T.ld + col);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (m0 + 16 * u < T.M) {
+                        const float xh = (gelu_f(zv[u]) - mn[u]) * rs[u];
+                        sg += dv[u] * xh; sb += dv[u];
+                    }
+                }
             }
         }
         red[0][rg][cc] = sg; red[1][rg][cc] = sb;
@@ -930,10 +956,17 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_lnbwd_kernel(const LnBwdTask*
             float g = 0.f, b = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { g += red[0][r][cc]; b += red[1][r][cc]; }
-            T.dgamma[col] = (col < T.width) ? g : 0.f;
-            T.dbeta[col] = (col < T.width) ? b : 0.f;
+            stg(T.dgamma + col, (col < T.width) ? g : 0.f);
+            stg(T.dbeta + col, (col < T.width) ? b : 0.f);
         }
     }
+}
+__global__ __launch_bounds__(FQL_THREADS) void fql_lnbwd_kernel(const LnBwdTask* __restrict__ tasks, int ntasks) {
+    __shared__ float red[2][16][16];
+    const int ti = find_task(tasks, ntasks, blockIdx.x);
+    const LnBwdTask& T = tasks[ti];
+    if (T.dq) lnbwd_body<true>(T, red);
+    else lnbwd_body<false>(T, red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1062,8 +1095,6 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_post_onestep_kernel(PostOsArg
     const int n = P.B * P.ad;
     for (int e = threadIdx.x; e < n; e += FQL_THREADS) {
         const int b = e / P.ad, a = e - b * P.ad;
-        P.X_ct[(size_t)b * P.inp_c + P.od + a] = clip1(P.A_os[(size_t)b * P.ap + a]);
-        P.X_c2[(size_t)b * P.inp_c + P.od + a] = clip1(P.A_os[(size_t)(P.B + b) * P.ap + a]);
         const float d = clip1(P.A_os[(size_t)(2 * P.B + b) * P.ap + a]) - P.w_act[(size_t)b * P.ap + a];
         se += d * d;
     }
