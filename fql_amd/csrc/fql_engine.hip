@@ -92,7 +92,7 @@ struct Leaf {
 // program = ordered ops with read/write sets -> levels -> launches
 // ------------------------------------------------------------------------------------------------
 enum OpType { OP_GEMM, OP_GEMM64, OP_WGRAD, OP_LNBWD, OP_PREP, OP_POSTOS, OP_EULER_FIN, OP_LOSS_CRITIC, OP_LOSS_Q, OP_LOSS_BC,
-              OP_LOSS_ACTOR, OP_BEGIN, OP_ADAM, OP_FINALIZE };
+              OP_LOSS_ACTOR, OP_ADAM, OP_FINALIZE };
 
 struct Op {
     OpType type;
@@ -166,6 +166,8 @@ struct fql_engine {
     std::vector<Leaf> leaves;
     int n_train_leaves = 0;
     AdamChunk* d_chunks = nullptr;
+    float* d_partials = nullptr;
+    int* d_leaf_range = nullptr;
     int n_chunks = 0;
 
     DevState* d_state = nullptr;
@@ -322,6 +324,13 @@ struct fql_engine {
         n_chunks = (int)ch.size();
         HIP_CHECK(hipMalloc((void**)&d_chunks, ch.size() * sizeof(AdamChunk)));
         HIP_CHECK(hipMemcpy(d_chunks, ch.data(), ch.size() * sizeof(AdamChunk), hipMemcpyHostToDevice));
+        std::vector<int> range(n_train_leaves + 1, 0);  // chunks are emitted leaf by leaf: contiguous ranges
+        for (const AdamChunk& c : ch) range[c.leaf + 1]++;
+        for (int i = 0; i < n_train_leaves; ++i) range[i + 1] += range[i];
+        HIP_CHECK(hipMalloc((void**)&d_leaf_range, range.size() * sizeof(int)));
+        HIP_CHECK(hipMemcpy(d_leaf_range, range.data(), range.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMalloc((void**)&d_partials, (size_t)n_chunks * 4 * sizeof(float)));
+        HIP_CHECK(hipMemset(d_partials, 0, (size_t)n_chunks * 4 * sizeof(float)));
     }
 
     const Leaf* find_leaf(const char* name) const {
@@ -873,16 +882,14 @@ struct fql_engine {
                 case OP_LOSS_ACTOR:
                     hipLaunchKernelGGL(fql_loss_actor_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.la);
                     break;
-                case OP_BEGIN:
-                    hipLaunchKernelGGL(fql_begin_step_kernel, dim3(1), dim3(64), 0, s, d_state, d_src);
-                    break;
                 case OP_ADAM: {
-                    AdamArgs a{P, G, Mu, Nu, P + n_train, d_chunks, d_state, (int)critic_size, cfg.lr, cfg.tau};
+                    AdamArgs a{P, G, Mu, Nu, P + n_train, d_chunks, d_state, d_partials, (int)critic_size, cfg.lr, cfg.tau};
                     hipLaunchKernelGGL(fql_adam_kernel, dim3(n_chunks), dim3(FQL_THREADS), 0, s, a);
                     break;
                 }
                 case OP_FINALIZE:
-                    hipLaunchKernelGGL(fql_finalize_kernel, dim3(1), dim3(64), 0, s, d_state, n_train_leaves, L.op.fin_mode);
+                    hipLaunchKernelGGL(fql_finalize_kernel, dim3(1), dim3(FQL_THREADS), 0, s,
+                                       FinalizeArgs{d_state, d_chunks, d_partials, d_leaf_range, n_chunks, n_train_leaves, L.op.fin_mode});
                     break;
             }
             if (par && L.record_after) {
@@ -1046,10 +1053,6 @@ struct fql_engine {
         emit_lane = 0;
         DevState* st = d_state;
         const void* INFO = &st->info[0];
-        Op b{};
-        b.type = OP_BEGIN;
-        b.writes = {st};
-        push(pr, b);
         Op a{};
         a.type = OP_ADAM;
         a.reads = {st, G};
@@ -1393,7 +1396,7 @@ int fql_destroy(fql_handle h) {
     for (auto& kv : h->evals) {
         for (void* p : kv.second->allocs) hipFree(p);
     }
-    hipFree(h->P); hipFree(h->G); hipFree(h->Mu); hipFree(h->Nu); hipFree(h->d_chunks); hipFree(h->d_state); hipFree(h->d_src);
+    hipFree(h->P); hipFree(h->G); hipFree(h->Mu); hipFree(h->Nu); hipFree(h->d_chunks); hipFree(h->d_partials); hipFree(h->d_leaf_range); hipFree(h->d_state); hipFree(h->d_src);
     if (h->h_src_ring) hipHostFree(h->h_src_ring);
     hipFree(h->ds_obs); hipFree(h->ds_act); hipFree(h->ds_rew); hipFree(h->ds_mask); hipFree(h->ds_nobs); hipFree(h->ds_row);
     if (h->stream) hipStreamDestroy(h->stream);

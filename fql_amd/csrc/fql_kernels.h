@@ -1241,6 +1241,7 @@ struct AdamArgs {
     float *P, *G, *Mu, *Nu, *T;  // T = target arena (same layout as the critic block at offset 0)
     const AdamChunk* chunks;
     DevState* st;
+    float* partials;  // [n_chunks][4]: sum of squares, max, min of the (scaled) gradient chunk
     int critic_size;
     float lr, tau;
 };
@@ -1250,20 +1251,11 @@ __device__ __forceinline__ int f2ord(float f) {
 }
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
 
-__global__ __launch_bounds__(FQL_THREADS) void fql_begin_step_kernel(DevState* st, const SrcDesc* src) {
-    // one thread: advance counters (optax count, TrainState.step) and the bias-correction powers
-    if (threadIdx.x == 0 && src->advance) {
-        st->adam_count += 1;
-        st->train_step += 1;
-        st->b1pow *= 0.9;
-        st->b2pow *= 0.999;
-    }
-}
-
 __global__ __launch_bounds__(FQL_THREADS) void fql_adam_kernel(AdamArgs A) {
     __shared__ float sh[4];
     const AdamChunk ch = A.chunks[blockIdx.x];  // <= 4096 elements, offset and length multiples of 4
-    const float c1 = (float)(1.0 - A.st->b1pow), c2 = (float)(1.0 - A.st->b2pow);
+    // optax bias correction with count = adam_count + 1 (the counters advance in the finalize kernel afterwards)
+    const float c1 = (float)(1.0 - A.st->b1pow * 0.9), c2 = (float)(1.0 - A.st->b2pow * 0.999);
     const float gsc = A.st->grad_scale;
     float ss = 0.f, mx = -INFINITY, mn = INFINITY;
     const int n4 = ch.len >> 2;
@@ -1272,58 +1264,86 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_adam_kernel(AdamArgs A) {
         const int i = threadIdx.x + it * FQL_THREADS;
         if (i < n4) {
             const int o = ch.off + 4 * i;
-            float4 g = *reinterpret_cast<const float4*>(A.G + o);
-            const float4 p = *reinterpret_cast<const float4*>(A.P + o);
-            float4 m = *reinterpret_cast<const float4*>(A.Mu + o);
-            float4 v = *reinterpret_cast<const float4*>(A.Nu + o);
-            float4 pn;
-            float* gp = &g.x; const float* pp = &p.x; float* mp = &m.x; float* vp = &v.x; float* pnp = &pn.x;
+            f32x4 g = ldg4(A.G + o);
+            const f32x4 p = ldg4(A.P + o);
+            f32x4 m = ldg4(A.Mu + o);
+            f32x4 v = ldg4(A.Nu + o);
+            f32x4 pn;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float ge = gp[e] * gsc;
-                mp[e] = 0.9f * mp[e] + 0.1f * ge;
-                vp[e] = 0.999f * vp[e] + 0.001f * ge * ge;
-                const float mh = mp[e] / c1, vh = vp[e] / c2;
-                pnp[e] = pp[e] - A.lr * (mh / (sqrtf(vh) + 1e-8f));
+                const float ge = g[e] * gsc;
+                m[e] = 0.9f * m[e] + 0.1f * ge;
+                v[e] = 0.999f * v[e] + 0.001f * ge * ge;
+                const float mh = m[e] / c1, vh = v[e] / c2;
+                pn[e] = p[e] - A.lr * (mh / (sqrtf(vh) + 1e-8f));
                 ss += ge * ge; mx = fmaxf(mx, ge); mn = fminf(mn, ge);
             }
-            *reinterpret_cast<float4*>(A.Mu + o) = m;
-            *reinterpret_cast<float4*>(A.Nu + o) = v;
-            *reinterpret_cast<float4*>(A.P + o) = pn;
+            stg4(A.Mu + o, m);
+            stg4(A.Nu + o, v);
+            stg4(A.P + o, pn);
             if (o < A.critic_size) {
-                float4 t = *reinterpret_cast<const float4*>(A.T + o);
-                t.x = p.x * A.tau + t.x * (1.0f - A.tau); t.y = p.y * A.tau + t.y * (1.0f - A.tau);
-                t.z = p.z * A.tau + t.z * (1.0f - A.tau); t.w = p.w * A.tau + t.w * (1.0f - A.tau);
-                *reinterpret_cast<float4*>(A.T + o) = t;
+                f32x4 t = ldg4(A.T + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = p[e] * A.tau + t[e] * (1.0f - A.tau);
+                stg4(A.T + o, t);
             }
         }
     }
+    // per-chunk partials, folded in fixed order by the finalize kernel: no atomics, bitwise reproducible stats
     const float tss = block_sum(ss, sh);
     const float tmx = block_max(mx, sh), tmn = -block_max(-mn, sh);
     if (threadIdx.x == 0) {
-        atomicAdd(&A.st->leaf_sumsq[ch.leaf], tss);
-        atomicMax(&A.st->gmax, f2ord(tmx));
-        atomicMin(&A.st->gmin, f2ord(tmn));
+        float* pp = A.partials + 4 * (size_t)blockIdx.x;
+        pp[0] = tss; pp[1] = tmx; pp[2] = tmn;
     }
 }
 
-__global__ void fql_finalize_kernel(DevState* st, int nleaves, int do_grad_stats) {
-    // grad/norm = sum over leaves of ||g_leaf||_2 (utils/flax_utils.py:141,149); target-critic leaves
-    // contribute zeros, which also bound grad/max >= 0 >= grad/min (F5).
-    if (threadIdx.x == 0) {
-        if (do_grad_stats) {
-            float nrm = 0.f;
-            for (int i = 0; i < nleaves; ++i) {
-                nrm += sqrtf(st->leaf_sumsq[i]);
-                st->leaf_sumsq[i] = 0.f;
-            }
-            st->info[10] = fmaxf(ord2f(st->gmax), 0.0f);
-            st->info[11] = fminf(ord2f(st->gmin), 0.0f);
-            st->info[12] = nrm;
-            st->gmax = f2ord(-INFINITY);
-            st->gmin = f2ord(INFINITY);
-            st->rng_step += 1;
+struct FinalizeArgs {
+    DevState* st;
+    const AdamChunk* chunks;
+    const float* partials;   // [n_chunks][4]
+    const int* leaf_range;   // [nleaves + 1] chunk index ranges (chunks of a leaf are contiguous)
+    int n_chunks, nleaves, do_grad_stats;
+};
+// grad/max, grad/min, grad/norm = sum over leaves of ||g_leaf||_2 (utils/flax_utils.py:139-157); target-critic leaves
+// contribute zeros, which bound grad/max >= 0 >= grad/min (F5).  Also advances optax count / TrainState.step / RNG step.
+__global__ __launch_bounds__(FQL_THREADS) void fql_finalize_kernel(FinalizeArgs A) {
+    __shared__ float sh[4];
+    __shared__ float leafn[128];
+    DevState* st = A.st;
+    if (!A.do_grad_stats) return;
+    float mx = -INFINITY, mn = INFINITY;
+    for (int cidx = threadIdx.x; cidx < A.n_chunks; cidx += FQL_THREADS) {
+        mx = fmaxf(mx, A.partials[4 * cidx + 1]);
+        mn = fminf(mn, A.partials[4 * cidx + 2]);
+    }
+    // 4 threads per leaf, each a contiguous quarter of the leaf's chunks, combined in fixed order
+    for (int base = 0; base < A.nleaves; base += 64) {
+        const int l = base + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+        float s = 0.f;
+        if (l < A.nleaves) {
+            const int b = A.leaf_range[l], e = A.leaf_range[l + 1];
+            const int per = (e - b + 3) >> 2;
+            const int lo = b + sub * per, hi = min(e, lo + per);
+            for (int cidx = lo; cidx < hi; ++cidx) s += A.partials[4 * cidx];
         }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (l < A.nleaves && sub == 0) leafn[l] = sqrtf(s);
+    }
+    const float tmx = block_max(mx, sh), tmn = -block_max(-mn, sh);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float nrm = 0.f;
+        for (int i = 0; i < A.nleaves; ++i) nrm += leafn[i];
+        st->info[10] = fmaxf(tmx, 0.0f);
+        st->info[11] = fminf(tmn, 0.0f);
+        st->info[12] = nrm;
+        st->rng_step += 1;
+        st->adam_count += 1;
+        st->train_step += 1;
+        st->b1pow *= 0.9;
+        st->b2pow *= 0.999;
     }
 }
 
