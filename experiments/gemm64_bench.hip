@@ -9,6 +9,7 @@
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 256, N = 512, K = argc > 2 ? atoi(argv[2]) : 512, P = argc > 3 ? atoi(argv[3]) : 7;
     const int flags = argc > 4 ? atoi(argv[4]) : (GF_BIAS | GF_GELU);
+    const int RI = argc > 5 ? atoi(argv[5]) : 2;
     hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     float *A0, *A1, *W, *b, *part; GemmTask* tb;
     CK(hipMalloc(&A0, (size_t)P * M * 512 * 4)); CK(hipMalloc(&A1, (size_t)P * M * 512 * 4)); CK(hipMalloc(&W, (size_t)P * K * N * 4)); CK(hipMalloc(&b, 4096 * 4));
@@ -24,9 +25,9 @@ int main(int argc, char** argv) {
             GemmTask t{};
             t.A = (pp ? A1 : A0) + (size_t)i * M * 512; t.C = (pp ? A0 : A1) + (size_t)i * M * 512; t.lda = K; t.ldc = N;
             t.B = W + (size_t)i * K * N; t.ldb = N; t.bias = b; t.M = M; t.N = N; t.K = K;
-            t.flags = flags; t.ntn = N / 64; t.tile0 = grid; t.ln_g = b; t.ln_b = b; t.ln_width = K;
+            t.flags = flags; t.ntn = N / 64; t.tile0 = grid; t.tmt = RI; t.ln_g = b; t.ln_b = b; t.ln_width = K;
             t.aux = part + (size_t)i * M * 16; t.aux2 = part + (size_t)i * M * 16; t.i0 = K / 64; t.i1 = N / 64;
-            grid += (M / 64) * t.ntn;
+            grid += (M / (32 * RI)) * t.ntn;
             h[pp * P + i] = t;
         }
     }

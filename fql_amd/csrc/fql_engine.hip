@@ -753,10 +753,11 @@ struct fql_engine {
                     std::vector<GemmTask> tb;
                     for (const Op* o : sel) {
                         GemmTask t = o->gemm;
-                        t.wk = 1; t.tmt = 4;
+                        static const int ri = getenv("FQL_G64_RI") ? atoi(getenv("FQL_G64_RI")) : 1;
+                        t.wk = 1; t.tmt = ri;  // row tiles per wave: workgroup tile (32 ri) x 64
                         t.ntn = t.N / 64;
                         t.tile0 = tile;
-                        tile += (t.M / 64) * t.ntn;
+                        tile += (t.M / (32 * ri)) * t.ntn;
                         tb.push_back(t);
                     }
                     L.lds = (size_t)(4 * 64 * 68 + 256) * sizeof(float);

@@ -212,14 +212,21 @@ __device__ __forceinline__ void gemm_load_chunk(float (&b)[32], const float* __r
             for (int s = 0; s < 4; ++s) b[4 * g + s] = ldg(bp + (size_t)(16 * g + s) * ldb);
     }
 }
-__device__ __forceinline__ void gemm_mma_chunk(f32x4& acc, const float (&b)[32], const float* arow) {
+// Two accumulator chains (even / odd k-groups): v_mfma_f32_16x16x4_f32 issues every 32 cycles but a dependent
+// accumulate needs 40, so a single chain runs at 80 % of the matrix rate.
+__device__ __forceinline__ void gemm_mma_chunk(f32x4& acc, f32x4& acc2, const float (&b)[32], const float* arow) {
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    for (int g = 0; g < 8; g += 2) {
         const float4 a = *reinterpret_cast<const float4*>(arow + 16 * g);
+        const float4 a2 = *reinterpret_cast<const float4*>(arow + 16 * g + 16);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[4 * g], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, b[4 * g + 4], acc2, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[4 * g + 1], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, b[4 * g + 5], acc2, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[4 * g + 2], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.z, b[4 * g + 6], acc2, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[4 * g + 3], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.w, b[4 * g + 7], acc2, 0, 0, 0);
     }
 }
 
@@ -244,17 +251,22 @@ __device__ __forceinline__ void gemm_wave(f32x4 (&acc)[TMT], const BAddr& ba, co
     const float* __restrict__ arow = lds_a + c * S + 4 * q;
     int g = gbeg;
     const int nfull = (gend - gbeg) >> 3;
+    f32x4 acc2[TMT];
+#pragma unroll
+    for (int r = 0; r < TMT; ++r) acc2[r] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int i = 0; i < nfull; i += 2) {
 #pragma unroll
-        for (int r = 0; r < TMT; ++r) gemm_mma_chunk(acc[r], b0, arow + r * 16 * S + 16 * g);
+        for (int r = 0; r < TMT; ++r) gemm_mma_chunk(acc[r], acc2[r], b0, arow + r * 16 * S + 16 * g);
         if (i + 2 < nfull) gemm_load_chunk<TRANS>(b0, ba.base + (size_t)(16 * (g + 16)) * ba.kstep, ba.ldb);
         if (i + 1 < nfull) {
 #pragma unroll
-            for (int r = 0; r < TMT; ++r) gemm_mma_chunk(acc[r], b1, arow + r * 16 * S + 16 * (g + 8));
+            for (int r = 0; r < TMT; ++r) gemm_mma_chunk(acc[r], acc2[r], b1, arow + r * 16 * S + 16 * (g + 8));
             if (i + 3 < nfull) gemm_load_chunk<TRANS>(b1, ba.base + (size_t)(16 * (g + 24)) * ba.kstep, ba.ldb);
         }
         g += 16;
     }
+#pragma unroll
+    for (int r = 0; r < TMT; ++r) acc[r] += acc2[r];
     g = gbeg + 8 * nfull;
     // tail: < 8 groups, all loads first
     const int nt = gend - g;
@@ -566,11 +578,12 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
 #ifndef FQL_GEMM_WAVES
 #define FQL_GEMM_WAVES 1
 #endif
+// (Passing the task by value in the kernel-argument segment was tried for single-task launches: slower -- the
+// kernarg segment is host-visible memory and a 200-byte struct costs more than one hop through the HBM table.)
 template <bool TMT2, bool KBIG>
 __global__ __launch_bounds__(FQL_THREADS, FQL_GEMM_WAVES) void fql_gemm16_kernel(const GemmTask* __restrict__ tasks, int ntasks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int ti = find_task(tasks, ntasks, blockIdx.x);
-    const GemmTask& T = tasks[ti];
+    const GemmTask& T = tasks[find_task(tasks, ntasks, blockIdx.x)];
     if (TMT2 && T.tmt == 2) {
         if (T.K <= 128) gemm16_body<2, 2, false>(T, lds);
         else if (!KBIG || T.K <= 512) gemm16_body<8, 2, false>(T, lds);
@@ -585,8 +598,7 @@ __global__ __launch_bounds__(FQL_THREADS, FQL_GEMM_WAVES) void fql_gemm16_kernel
 template <bool KBIG>
 __global__ __launch_bounds__(FQL_THREADS) void fql_gemm16_euler_kernel(const GemmTask* __restrict__ tasks, int ntasks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int ti = find_task(tasks, ntasks, blockIdx.x);
-    const GemmTask& T = tasks[ti];
+    const GemmTask& T = tasks[find_task(tasks, ntasks, blockIdx.x)];
     if (T.K <= 128) gemm16_body<2, 1, true>(T, lds);
     else if (!KBIG || T.K <= 512) gemm16_body<8, 1, true>(T, lds);
     else gemm16_body<16, 1, true>(T, lds);
@@ -602,14 +614,17 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_gemm16_euler_kernel(const Gem
 // them in fixed order (deterministic) into mean / rstd before staging (utils/networks.py:58).
 // ------------------------------------------------------------------------------------------------
 #define G64_S 68  // LDS row stride (floats): 64 + 4, keeps 16-byte alignment and spreads banks
-template <bool transb>
+// RI = 16-row MFMA tiles per wave along M: 2 -> 64 x 64 workgroup tile, 1 -> 32 x 64 (half the serial MFMA time per
+// workgroup and twice the workgroups: the side lane's levels are latency chains too, so the smaller tile wins there)
+template <bool transb, int RI>
 __device__ __forceinline__ void gemm64_body(const GemmTask& T, float* lds) {
-    float* As = lds;                    // [2][64][G64_S]
-    float* Bs = lds + 2 * 64 * G64_S;   // [2][64][G64_S]   ([k][n], or [n][k] when GF_TRANS_B)
-    float* part = Bs + 2 * 64 * G64_S;  // [2][64][2] LN partial sums of the epilogue
+    constexpr int TM = 32 * RI;
+    float* As = lds;                    // [2][TM][G64_S]
+    float* Bs = lds + 2 * TM * G64_S;   // [2][64][G64_S]   ([k][n], or [n][k] when GF_TRANS_B)
+    float* part = Bs + 2 * 64 * G64_S;  // [2][TM][2] LN partial sums of the epilogue
     const int local = blockIdx.x - T.tile0;
     const int tm = local / T.ntn, tn = local - tm * T.ntn;
-    const int row0 = tm * 64, n0 = tn * 64;
+    const int row0 = tm * TM, n0 = tn * 64;
     const int K = T.K;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1;
@@ -617,21 +632,24 @@ __device__ __forceinline__ void gemm64_body(const GemmTask& T, float* lds) {
     const int flags = T.flags;
     const bool a_ln = (flags & GF_A_LN) != 0;
     const bool ln_wr = (flags & GF_LN_WRITE) && tn == 0;
-    // staging coordinates: 4 float4 per thread per operand; f = tid + 256 i -> row f / 16, float4 column f % 16
+    // staging coordinates: f = tid + 256 i -> row f / 16, float4 column f % 16 (2 RI float4 per thread for A, 4 for B)
     const int sr = tid >> 4, sc4 = tid & 15;
-    float mean[4] = {0.f, 0.f, 0.f, 0.f}, rstd[4] = {1.f, 1.f, 1.f, 1.f};
+    constexpr int NRA = 2 * RI;
+    float mean[NRA], rstd[NRA];
+#pragma unroll
+    for (int i = 0; i < NRA; ++i) { mean[i] = 0.f; rstd[i] = 1.f; }
     if (a_ln) {
         const int ntin = T.i0;  // 64-column tiles of the producing layer (<= 16: widths <= 1024)
         const float inv = 1.0f / (float)T.ln_width;
-        f32x4 pv[4][8];
+        f32x4 pv[NRA][8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NRA; ++i) {
             const float* pp = T.aux2 + (size_t)(row0 + sr + 16 * i) * ((2 * ntin + 3) & ~3);  // rows padded to 16 B
 #pragma unroll
             for (int t = 0; t < 8; ++t) pv[i][t] = ldg4(pp + 4 * min(t, (ntin - 1) >> 1));  // 2 tiles per float4, clamped
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NRA; ++i) {
             const int row = row0 + sr + 16 * i;
             float s = 0.f, s2 = 0.f;
 #pragma unroll
@@ -645,20 +663,19 @@ __device__ __forceinline__ void gemm64_body(const GemmTask& T, float* lds) {
             if (ln_wr && sc4 == 0) { stg(T.ln_stats + 2 * row, mean[i]); stg(T.ln_stats + 2 * row + 1, rstd[i]); }
         }
     }
-    f32x4 ra0[4], rb0[4], ra1[4], rb1[4];  // two register sets: a chunk's loads stay in flight across two compute phases
+    f32x4 ra0[NRA], rb0[4], ra1[NRA], rb1[4];  // two register sets: a chunk's loads stay in flight across two compute phases
     const float* __restrict__ Ag = T.A + (size_t)(row0 + sr) * T.lda + 4 * sc4;
     const float* __restrict__ Bg = transb ? T.B + (size_t)(n0 + sr) * T.ldb + 4 * sc4 : T.B + (size_t)sr * T.ldb + n0 + 4 * sc4;
-    auto load_chunk = [&](f32x4 (&ra)[4], f32x4 (&rb)[4], int k0) {  // K is a multiple of 64: no guards, unconditional loads
+    auto load_chunk = [&](f32x4 (&ra)[NRA], f32x4 (&rb)[4], int k0) {  // K is a multiple of 64: no guards, unconditional loads
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = ldg4(Ag + (size_t)(16 * i) * T.lda + k0);
-            rb[i] = transb ? ldg4(Bg + (size_t)(16 * i) * T.ldb + k0) : ldg4(Bg + (size_t)(k0 + 16 * i) * T.ldb);
-        }
+        for (int i = 0; i < NRA; ++i) ra[i] = ldg4(Ag + (size_t)(16 * i) * T.lda + k0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[i] = transb ? ldg4(Bg + (size_t)(16 * i) * T.ldb + k0) : ldg4(Bg + (size_t)(k0 + 16 * i) * T.ldb);
         if (a_ln) {
             const int k = k0 + 4 * sc4;
             const f32x4 g = ldg4(T.ln_g + k), be = ldg4(T.ln_b + k);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NRA; ++i) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float v = (ra[i][e] - mean[i]) * rstd[i] * g[e] + be[e];
@@ -668,30 +685,29 @@ __device__ __forceinline__ void gemm64_body(const GemmTask& T, float* lds) {
             }
         }
     };
-    auto store_chunk = [&](const f32x4 (&ra)[4], const f32x4 (&rb)[4], int buf) {
-        float* a = As + buf * 64 * G64_S;
+    auto store_chunk = [&](const f32x4 (&ra)[NRA], const f32x4 (&rb)[4], int buf) {
+        float* a = As + buf * TM * G64_S;
         float* b = Bs + buf * 64 * G64_S;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(a + (sr + 16 * i) * G64_S + 4 * sc4) = ra[i];
-            *reinterpret_cast<f32x4*>(b + (sr + 16 * i) * G64_S + 4 * sc4) = rb[i];
-        }
-    };
-    f32x4 acc[2][2];
+        for (int i = 0; i < NRA; ++i) *reinterpret_cast<f32x4*>(a + (sr + 16 * i) * G64_S + 4 * sc4) = ra[i];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(b + (sr + 16 * i) * G64_S + 4 * sc4) = rb[i];
+    };
+    f32x4 acc[RI][2];
+#pragma unroll
+    for (int i = 0; i < RI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float bias0 = (flags & GF_BIAS) ? ldg(T.bias + n0 + 32 * wc + c) : 0.f;
     const float bias1 = (flags & GF_BIAS) ? ldg(T.bias + n0 + 32 * wc + 16 + c) : 0.f;
 
     auto compute = [&](int buf) {
-        const float* a = As + buf * 64 * G64_S + (32 * wr + c) * G64_S + 4 * q;
+        const float* a = As + buf * TM * G64_S + (16 * RI * wr + c) * G64_S + 4 * q;
         const float* b = Bs + buf * 64 * G64_S;
-        f32x4 fa[2][2], fb[2][2];  // [pipeline slot][tile]: group g+1's fragments are read while group g multiplies
+        f32x4 fa[2][RI], fb[2][2];  // [pipeline slot][tile]: group g+1's fragments are read while group g multiplies
         auto read_frags = [&](int slot, int g) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[slot][i] = *reinterpret_cast<const f32x4*>(a + 16 * i * G64_S + 16 * g);
+            for (int i = 0; i < RI; ++i) fa[slot][i] = *reinterpret_cast<const f32x4*>(a + 16 * i * G64_S + 16 * g);
             if (transb) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) fb[slot][j] = *reinterpret_cast<const f32x4*>(b + (32 * wc + 16 * j + c) * G64_S + 16 * g + 4 * q);
@@ -709,7 +725,7 @@ __device__ __forceinline__ void gemm64_body(const GemmTask& T, float* lds) {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < RI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[g & 1][i][s], fb[g & 1][j][s], acc[i][j], 0, 0, 0);
         }
@@ -740,12 +756,12 @@ __device__ __forceinline__ void gemm64_body(const GemmTask& T, float* lds) {
     }
 
     // ---- epilogue. C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
-    float s1[2][4], s2[2][4];
+    float s1[RI][4], s2[RI][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RI; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = row0 + 32 * wr + 16 * i + 4 * q + r;
+            const int row = row0 + 16 * RI * wr + 16 * i + 4 * q + r;
             s1[i][r] = 0.f; s2[i][r] = 0.f;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -762,23 +778,23 @@ __device__ __forceinline__ void gemm64_body(const GemmTask& T, float* lds) {
     }
     if (flags & GF_LN_PART) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < RI; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float a = s1[i][r], b = s2[i][r];
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
                 if (c == 0) {
-                    const int rl = 32 * wr + 16 * i + 4 * q + r;
-                    part[(wc * 64 + rl) * 2] = a;
-                    part[(wc * 64 + rl) * 2 + 1] = b;
+                    const int rl = 16 * RI * wr + 16 * i + 4 * q + r;
+                    part[(wc * TM + rl) * 2] = a;
+                    part[(wc * TM + rl) * 2 + 1] = b;
                 }
             }
         __syncthreads();
-        if (tid < 64) {
+        if (tid < TM) {
             float* pp = T.aux + (size_t)(row0 + tid) * ((2 * T.i1 + 3) & ~3) + 2 * tn;
-            stg(pp, part[tid * 2] + part[(64 + tid) * 2]);
-            stg(pp + 1, part[tid * 2 + 1] + part[(64 + tid) * 2 + 1]);
+            stg(pp, part[tid * 2] + part[(TM + tid) * 2]);
+            stg(pp + 1, part[tid * 2 + 1] + part[(TM + tid) * 2 + 1]);
         }
     }
 }
@@ -787,8 +803,13 @@ __global__ __launch_bounds__(FQL_THREADS, 2) void fql_gemm64_kernel(const GemmTa
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int ti = find_task(tasks, ntasks, blockIdx.x);
     const GemmTask& T = tasks[ti];
-    if (T.flags & GF_TRANS_B) gemm64_body<true>(T, lds);
-    else gemm64_body<false>(T, lds);
+    if (T.tmt == 1) {
+        if (T.flags & GF_TRANS_B) gemm64_body<true, 1>(T, lds);
+        else gemm64_body<false, 1>(T, lds);
+    } else {
+        if (T.flags & GF_TRANS_B) gemm64_body<true, 2>(T, lds);
+        else gemm64_body<false, 2>(T, lds);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
