@@ -91,7 +91,7 @@ struct Leaf {
 // ------------------------------------------------------------------------------------------------
 // program = ordered ops with read/write sets -> levels -> launches
 // ------------------------------------------------------------------------------------------------
-enum OpType { OP_GEMM, OP_GEMM64, OP_WGRAD, OP_LNBWD, OP_PREP, OP_POSTOS, OP_EULER_FIN, OP_LOSS_CRITIC, OP_LOSS_Q, OP_LOSS_BC,
+enum OpType { OP_GEMM, OP_GEMM64, OP_WGRAD, OP_LNBWD, OP_PREP, OP_POSTOS, OP_EULER_FIN, OP_PEC, OP_LOSS_CRITIC, OP_LOSS_Q, OP_LOSS_BC,
               OP_LOSS_ACTOR, OP_ADAM, OP_FINALIZE };
 
 struct Op {
@@ -107,6 +107,7 @@ struct Op {
     LossBcArgs lb;
     LossActorArgs la;
     EulerFinishArgs ef;
+    PecArgs pec;
     int fin_mode = 0;
     int level = 0;
     int lane = 0;            // 0 = critical lane (Euler chain, one-step backward), 1 = side lane
@@ -186,8 +187,11 @@ struct fql_engine {
     float *X_os = nullptr, *X_bc = nullptr, *X_eu = nullptr, *X_c1 = nullptr, *X_c2 = nullptr, *X_ct = nullptr;
     float *vel = nullptr, *w_rew = nullptr, *w_mask = nullptr, *w_act = nullptr, *tgt = nullptr;
     float *X_e0 = nullptr, *C0 = nullptr, *Abuf[2] = {nullptr, nullptr}, *Vpart = nullptr;  // fused Euler chain
-    bool fused_euler = false;
+    bool fused_euler = false, use_pec = false;
     int vp_tiles = 0;
+    unsigned* pec_cnt = nullptr;   // [teams][3 flow_steps] arrival counters + 1 error word at the end
+    size_t pec_cnt_bytes = 0;
+    int num_cus = 0;
     PassBuf p_os, p_os_bwd, p_bc, p_eu, p_c1[2], p_c2[2], p_ct[2];
     Program prog_fwdbwd, prog_opt, prog_loss;
     bool began = false;
@@ -490,6 +494,38 @@ struct fql_engine {
             }
             push(pr, op);
         }
+    }
+
+    // The whole Euler chain in one persistent launch (fql_euler_persistent_kernel): C0 GEMM, then teams of H/32
+    // workgroups hand 16-row activation tiles to each other through L2.
+    void emit_euler_persistent(Program& pr) {
+        const Net& n = nets[NET_BC];
+        const int od = cfg.obs_dim, ad = cfg.act_dim, ap = pad16(ad), inp_b = n.in_p();
+        const Layer& l0 = n.layers[0];
+        {
+            Op op{};
+            op.type = OP_GEMM;
+            GemmTask& t = op.gemm;
+            t.A = X_e0; t.lda = l0.in_p; t.B = P + l0.w; t.ldb = l0.out_p; t.bias = P + l0.b; t.C = C0; t.ldc = l0.out_p;
+            t.M = B; t.N = l0.out_p; t.K = l0.in_p; t.flags = GF_BIAS;
+            op.reads = {X_e0, t.B};
+            op.writes = {C0};
+            push(pr, op);
+        }
+        Op op{};
+        op.type = OP_PEC;
+        PecArgs& a = op.pec;
+        a.C0 = C0; a.a0 = X_eu + od; a.lda0 = inp_b;
+        a.W0act = P + l0.w + (size_t)od * l0.out_p;
+        for (int l = 0; l < 3; ++l) { a.W[l] = P + n.layers[l + 1].w; a.b[l] = P + n.layers[l + 1].b; }
+        a.W4 = P + n.layers[4].w; a.b4 = P + n.layers[4].b;
+        a.Hbuf[0] = p_eu.g[1]; a.Hbuf[1] = p_eu.g[2];
+        a.Vpart = Vpart; a.tgt = tgt;
+        a.cnt = pec_cnt; a.err = pec_cnt + (size_t)(B / 16) * 3 * cfg.flow_steps;
+        a.M = B; a.ad = ad; a.ap = ap; a.flow_steps = cfg.flow_steps; a.nteams = B / 16;
+        op.reads = {C0, X_eu};
+        op.writes = {tgt, p_eu.g[1], p_eu.g[2], Vpart};
+        push(pr, op);
     }
 
     // Euler chain with 3 launches per step instead of 5 (agents/fql.py:155-171): [fold head partials -> a_s; layer 0 as a
@@ -841,6 +877,8 @@ struct fql_engine {
         static const int only_lane = getenv("FQL_ONLY_LANE") ? atoi(getenv("FQL_ONLY_LANE")) : -1;  // timing experiments
         for (Launch& L : pr.launches) {
             if (only_lane >= 0 && pr.two_lanes && L.lane != only_lane) continue;
+            static const int skip_lane = getenv("FQL_SKIP_LANE") ? atoi(getenv("FQL_SKIP_LANE")) : -1;
+            if (skip_lane >= 0 && pr.two_lanes && L.lane == skip_lane && L.type != OP_PREP) continue;
             hipStream_t s = par ? ls[L.lane] : s0;
             if (par)
                 for (int w : L.waits) if (pr.launches[w].ev) HIP_CHECK(hipStreamWaitEvent(s, pr.launches[w].ev, 0));
@@ -868,6 +906,15 @@ struct fql_engine {
                 case OP_POSTOS:
                     hipLaunchKernelGGL(fql_post_onestep_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.postos);
                     break;
+                case OP_PEC: {
+                    const PecArgs& a = L.op.pec;
+                    const int T = cfg.actor_hidden[0] / 32;
+                    HIP_CHECK(hipMemsetAsync(a.cnt, 0, pec_cnt_bytes, s));
+                    const size_t lds = ((size_t)16 * (cfg.actor_hidden[0] + 4) + 1024 + 512 + 576) * sizeof(float);
+                    if (cfg.actor_hidden[0] == 512) hipLaunchKernelGGL((fql_euler_persistent_kernel<512>), dim3(a.nteams * T), dim3(FQL_THREADS), lds, s, a);
+                    else hipLaunchKernelGGL((fql_euler_persistent_kernel<256>), dim3(a.nteams * T), dim3(FQL_THREADS), lds, s, a);
+                    break;
+                }
                 case OP_EULER_FIN:
                     hipLaunchKernelGGL(fql_euler_finish_kernel, dim3((L.op.ef.M * L.op.ef.ad + FQL_THREADS - 1) / FQL_THREADS), dim3(FQL_THREADS), 0, s, L.op.ef);
                     break;
@@ -1020,7 +1067,8 @@ struct fql_engine {
         // Euler chain through the BC flow (fql.py:155-171): flow_steps sequential forwards
         place("eu", 0, false);
         const int fs = cfg.flow_steps;
-        if (fused_euler) emit_euler_fused(pr);
+        if (use_pec) emit_euler_persistent(pr);
+        else if (fused_euler) emit_euler_fused(pr);
         else
         for (int s = 0; s < fs; ++s)
             emit_forward(pr, p_eu, false, GF_EULER | (s == fs - 1 ? GF_EULER_LAST : 0), X_eu, tgt, 1.0f / (float)fs,
@@ -1112,6 +1160,17 @@ struct fql_engine {
                 vp_tiles = (nb.layers[nh - 1].out_p / 16 + 1) / 2;
                 if (vp_tiles > 32) fused_euler = false;
                 Vpart = dalloc(W, (size_t)std::max(vp_tiles, 1) * B * ap);
+                // persistent chain: one launch for all flow_steps x layers; needs every workgroup resident (1 per CU)
+                const int H = nb.layers[0].out_p;
+                bool same = nh == 4 && (H == 512 || H == 256);
+                for (int l = 0; l < nh; ++l) same = same && nb.layers[l].out_p == H && nb.layers[l].out == H;
+                // opt-in (FQL_PEC=1): alone the chain drops from 331 to 220 us, but beside the other lanes the update time is
+                // unchanged on this box (the lanes barely overlap), so the default stays with plain launches
+                use_pec = fused_euler && same && getenv("FQL_PEC") != nullptr && (B / 16) * (H / 32) <= num_cus;
+                if (use_pec) {
+                    pec_cnt_bytes = (((size_t)(B / 16) * 3 * cfg.flow_steps + 1) * sizeof(unsigned) + 15) & ~(size_t)15;
+                    pec_cnt = (unsigned*)dalloc(W, pec_cnt_bytes / sizeof(float));
+                }
             }
         }
         p_os = make_pass(W, NET_OS, 3 * B, X_os, false, false);
@@ -1356,6 +1415,7 @@ int fql_create(const fql_config* cfg, uint64_t seed, fql_handle* out) {
             return FQL_E_NODEVICE;
         }
         // (stream priorities were tried for the lanes: no gain with two streams, a 4x slowdown with three)
+        h->num_cus = prop.multiProcessorCount;
         HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
         HIP_CHECK(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
@@ -1626,6 +1686,11 @@ int fql_read_info(fql_handle h, float* info13_host) {
     FQL_TRY(h, {
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipMemcpy(info13_host, &h->d_state->info[0], FQL_NUM_INFO * sizeof(float), hipMemcpyDeviceToHost));
+        if (h->use_pec) {
+            unsigned e = 0;
+            HIP_CHECK(hipMemcpy(&e, h->pec_cnt + (size_t)(h->B / 16) * 3 * h->cfg.flow_steps, sizeof e, hipMemcpyDeviceToHost));
+            if (e) throw HipError{"persistent Euler chain: a team hand-off timed out (results of this update are invalid)"};
+        }
     });
 }
 

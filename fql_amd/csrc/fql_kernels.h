@@ -1390,6 +1390,290 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_euler_finish_kernel(EulerFini
     stg(P.tgt + (size_t)r * P.ap + j, clip1(ldg(P.a_in + (size_t)r * P.a_ld + j) + (sum + ldg(P.eb + j)) * P.scale));
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent Euler chain (agents/fql.py:155-171): the whole 10-step x (layers 0..3 + head) chain in ONE launch.
+//
+// A kernel boundary costs ~1.6 us plus ~2.5 us of cold first loads (the per-XCD L2s are written back and
+// invalidated at every boundary), 30 times per update.  Here the 16 workgroups that own one 16-row tile of the
+// batch (a "team": one 32-column slice of every hidden layer each) hand their 16 x 32 output tiles to each other
+// through L2 with the write-through / counter hand-off of the CDNA4 guide (G16 recipe, counter form):
+//   producer: every byte stored sc1 (agent-scope relaxed atomics, 8 B) -> each storing wave s_waitcnt vmcnt(0) ->
+//             __syncthreads() -> one lane: relaxed agent-scope fetch_add on the (team, phase) counter;
+//   consumer: one lane polls that counter (relaxed, agent scope, s_sleep between polls, wall-clock bounded) ->
+//             __syncthreads() -> every load of the handed-off bytes is an sc1 (agent-scope relaxed atomic) load.
+// Results do not depend on placement; teams are mapped to one XCD only for speed.  Every counter is zeroed by a
+// memset node in front of the launch; a spin that times out sets an error word and falls through, so the grid
+// always drains.  The hidden-layer weights this workgroup needs (K-half x 16 columns x 3 layers per wave) live in
+// 192 VGPRs for the whole chain, as do its slice of C0 = obs W0 + b0 and the action/t rows of W0: in steady state
+// a phase loads nothing but the 32 KB activation tile.
+// ------------------------------------------------------------------------------------------------
+struct PecArgs {
+    const float* C0;      // [M, H]  obs W0 + b0 (loop invariant)
+    const float* a0;      // [M, lda0] initial actions (noise z): X_eu + obs_dim
+    const float* W0act;   // W0 rows of (action block, t): [ad + 1 (+ zero rows)][H]
+    const float* W[3];    // hidden kernels of layers 1..3, [H][H]
+    const float* b[3];    // their biases
+    const float* W4;      // head kernel [H][ap]
+    const float* b4;      // head bias [ap]
+    float* Hbuf[2];       // [M, H] activation ping-pong
+    float* Vpart;         // [T][M][ap] head partials
+    float* tgt;           // [M, ap] out: clip(a_n)
+    unsigned* cnt;        // [teams][phases] arrival counters (zeroed before the launch)
+    unsigned* err;        // set to 1 if a wait timed out
+    int M, ad, ap, lda0, flow_steps, nteams;
+};
+
+typedef unsigned long long fql_u64;
+__device__ __forceinline__ fql_u64 ld_sc1_u64(const float* p) {
+    return __hip_atomic_load((const FQL_GAS fql_u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1_u64(float* p, fql_u64 v) {
+    __hip_atomic_store((FQL_GAS fql_u64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ fql_u64 pack2(float a, float b) {
+    return (fql_u64)__float_as_uint(a) | ((fql_u64)__float_as_uint(b) << 32);
+}
+// one lane waits until *c == want (relaxed agent-scope polls); bounded by wall clock (100 MHz ticks)
+__device__ __forceinline__ void pec_wait(unsigned* c, unsigned want, unsigned* err) {
+    const fql_u64 t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load((FQL_GAS unsigned*)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(2);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {  // 200 ms: something is badly wrong, drain the grid
+            __hip_atomic_store((FQL_GAS unsigned*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}
+
+template <int H>  // hidden width (all four hidden layers), multiple of 64; T = H / 32 members per team
+__global__ __launch_bounds__(FQL_THREADS) void fql_euler_persistent_kernel(const PecArgs P) {
+    constexpr int T = H / 32, S = H + 4, G2 = H / 32;  // G2 = k-groups (of 16) per K-half
+    constexpr int CT = H / 64;                          // layer-0 column tiles per wave
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* red = lds + 16 * S;   // [2 column tiles][64] float4: K-split partials
+    float* ea = red + 1024;      // [16][32] current actions a_s (persistent across steps)
+    float* hs = ea + 512;        // [16][36] staging: output tile / last-hidden tile
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 15, q = lane >> 4;
+    const int nt = wave & 1, kp = wave >> 1;
+    // team / member mapping: members of a team share blockIdx % 8 (one XCD under round-robin placement: speed only)
+    int team, mem;
+    if (P.nteams % 8 == 0) {
+        const int x = blockIdx.x & 7, qq = blockIdx.x >> 3;
+        mem = qq % T; team = x + 8 * (qq / T);
+    } else {
+        team = blockIdx.x / T; mem = blockIdx.x % T;
+    }
+    const int row0 = team * 16, n0 = mem * 32 + nt * 16;
+    const int M = P.M, ad = P.ad, ap = P.ap;
+    unsigned* cnt = P.cnt + (size_t)team * (3 * P.flow_steps);
+
+    // ---- operands.  The hidden-layer B fragments (K-half x 16 columns = 4 G2 VGPRs) are re-fetched every phase, but
+    // BEFORE the wait for the team (they do not depend on the hand-off) and from an L2 that is never invalidated
+    // inside this launch; keeping all three layers resident instead (192 VGPRs) would push the kernel to 450
+    // VGPRs and evict every other lane's waves from the CUs for the length of the chain.
+    float wb[4 * G2];  // element (k = 16 (kp G2 + g) + 4 q + s, n0 + c) of the current layer
+    auto load_w = [&](const float* Wl) {
+        // the per-lane base is made opaque so the 4 G2 load addresses are formed here, next to the loads: hoisted
+        // out of the step loop they would occupy >100 VGPR pairs for the whole kernel
+        const float* base = Wl + (size_t)(16 * kp * G2 + 4 * q) * H + n0 + c;
+        asm volatile("" : "+v"(base));
+#pragma unroll
+        for (int g = 0; g < G2; ++g)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) wb[4 * g + s4] = ldg(base + (size_t)(16 * g + s4) * H);
+    };
+    float bias[3];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) bias[l] = ldg(P.b[l] + n0 + c);
+    float bw4[8];       // head kernel rows of this workgroup's 32 hidden columns (used by wave 0)
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) bw4[4 * g + s4] = ldg(P.W4 + (size_t)(mem * 32 + 16 * g + 4 * q + s4) * ap + c);
+    // a_0 (+ zero fill of the [16][32] block); column ad carries t_s
+    for (int e = tid; e < 16 * 32; e += FQL_THREADS) {
+        const int r = e >> 5, j = e & 31;
+        ea[e] = (j < ad) ? ldg(P.a0 + (size_t)(row0 + r) * P.lda0 + j) : 0.f;
+    }
+    const float inv_steps = 1.0f / (float)P.flow_steps;
+    int phase = 0;  // global phase index of this team: 3 per Euler step
+
+    auto gemm_phase = [&](const float (&wl)[4 * G2]) -> f32x4 {  // A tile in LDS -> 16 x 16 accumulator (kp 0 holds the sum)
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+        const float* arow = lds + c * S + 4 * q + 16 * kp * G2;
+#pragma unroll
+        for (int g = 0; g < G2; g += 2) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * g);
+            const f32x4 a2 = *reinterpret_cast<const f32x4*>(arow + 16 * g + 16);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], wl[4 * g + s4], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[s4], wl[4 * g + 4 + s4], acc2, 0, 0, 0);
+            }
+        }
+        acc += acc2;
+        if (kp == 1) *reinterpret_cast<f32x4*>(&red[(nt * 64 + lane) * 4]) = acc;
+        __syncthreads();
+        if (kp == 0) acc += *reinterpret_cast<const f32x4*>(&red[(nt * 64 + lane) * 4]);
+        return acc;
+    };
+    auto signal = [&]() {  // every storing wave drained, then one lane announces this workgroup's tile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add((FQL_GAS unsigned*)(cnt + phase), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ++phase;
+    };
+    auto wait_prev = [&]() {  // all T members have published phase - 1
+        if (tid == 0) pec_wait(cnt + phase - 1, (unsigned)T, P.err);
+        __syncthreads();
+    };
+    auto publish_tile = [&](const f32x4& acc, float bl, float* dst) {  // GELU tile -> hs -> 8-byte sc1 stores of whole rows
+        if (kp == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hs[(4 * q + i) * 36 + 16 * nt + c] = gelu_f(acc[i] + bl);
+        }
+        __syncthreads();
+        {   // 16 rows x 32 floats = 256 pairs: one 8-byte store per thread
+            const int r = tid >> 4, j2 = (tid & 15) * 2;
+            st_sc1_u64(dst + (size_t)(row0 + r) * H + mem * 32 + j2, pack2(hs[r * 36 + j2], hs[r * 36 + j2 + 1]));
+        }
+    };
+    auto load_tile = [&](const float* src) {  // 16 x H floats, sc1 loads, 8 B each
+        constexpr int NP = 16 * H / 2 / FQL_THREADS;  // pairs per thread
+        fql_u64 v[NP];
+        // thread t covers pairs f = t + 256 i: row = i (256 pairs = one row of 512 floats when H = 512) -- keep the
+        // generic form but from an opaque base so the NP addresses are not hoisted out of the step loop
+        const float* sb = src + (size_t)row0 * H;
+        asm volatile("" : "+v"(sb));
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int f = tid + i * FQL_THREADS;
+            const int r = f / (H / 2), j2 = (f - r * (H / 2)) * 2;
+            v[i] = ld_sc1_u64(sb + (size_t)r * H + j2);
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int f = tid + i * FQL_THREADS;
+            const int r = f / (H / 2), j2 = (f - r * (H / 2)) * 2;
+            lds[r * S + j2] = __uint_as_float((unsigned)v[i]);
+            lds[r * S + j2 + 1] = __uint_as_float((unsigned)(v[i] >> 32));
+        }
+    };
+
+#pragma clang loop unroll(disable)
+    for (int s = 0; s < P.flow_steps; ++s) {
+        // ---------------- phase A: fold head partials -> a_s ; layer 0 (rank update of C0) ; layer 1
+        load_w(P.W[0]);
+        f32x4 c0f[CT];      // C0 in C layout for this wave's layer-0 column tiles (wave + 4 t)
+        float wf[CT][4];    // W0 action/t rows for the same tiles
+        {
+            const float* cb = P.C0 + (size_t)(row0 + 4 * q) * H + 16 * wave + c;
+            const float* wb0 = P.W0act + (size_t)(4 * q) * H + 16 * wave + c;
+            asm volatile("" : "+v"(cb), "+v"(wb0));
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c0f[t][i] = ldg(cb + (size_t)i * H + 64 * t);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) wf[t][s4] = ldg(wb0 + (size_t)s4 * H + 64 * t);
+            }
+        }
+        if (s > 0) {
+            wait_prev();
+            if (tid < 16 * 16) {
+                const int r = tid >> 4, j = tid & 15;
+                if (j < ad) {
+                    float sum = 0.f;
+                    float pv[T];
+#pragma unroll
+                    for (int tp = 0; tp < T; ++tp) pv[tp] = __uint_as_float((unsigned)__hip_atomic_load(
+                        (const FQL_GAS unsigned*)(P.Vpart + ((size_t)tp * M + row0 + r) * ap + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+                    for (int tp = 0; tp < T; ++tp) sum += pv[tp];
+                    ea[r * 32 + j] += (sum + ldg(P.b4 + j)) * inv_steps;
+                }
+            }
+        }
+        if (tid < 16) ea[tid * 32 + ad] = (float)s * inv_steps;  // t_s
+        __syncthreads();
+        {
+            const f32x4 af = *reinterpret_cast<const f32x4*>(&ea[c * 32 + 4 * q]);
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                f32x4 h = c0f[t];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) h = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s4], wf[t][s4], h, 0, 0, 0);
+                const int ct = wave + 4 * t;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lds[(4 * q + i) * S + 16 * ct + c] = gelu_f(h[i]);
+            }
+        }
+        __syncthreads();
+        {
+            const f32x4 acc = gemm_phase(wb);
+            publish_tile(acc, bias[0], P.Hbuf[0]);
+            signal();
+        }
+        // ---------------- phase B: layer 2
+        load_w(P.W[1]);
+        wait_prev();
+        load_tile(P.Hbuf[0]);
+        __syncthreads();
+        {
+            const f32x4 acc = gemm_phase(wb);
+            publish_tile(acc, bias[1], P.Hbuf[1]);
+            signal();
+        }
+        // ---------------- phase C: layer 3 + head partial
+        load_w(P.W[2]);
+        wait_prev();
+        load_tile(P.Hbuf[1]);
+        __syncthreads();
+        {
+            const f32x4 acc = gemm_phase(wb);
+            if (kp == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hs[(4 * q + i) * 36 + 16 * nt + c] = gelu_f(acc[i] + bias[2]);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                f32x4 pa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(&hs[c * 36 + 16 * g + 4 * q]);
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) pa = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s4], bw4[4 * g + s4], pa, 0, 0, 0);
+                }
+                if (c < ap) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        __hip_atomic_store((FQL_GAS unsigned*)(P.Vpart + ((size_t)mem * M + row0 + 4 * q + i) * ap + c),
+                                           __float_as_uint(pa[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            signal();
+        }
+    }
+    // ---------------- final: member 0 folds the last partials and writes clip(a_n)
+    if (mem == 0) {
+        wait_prev();
+        if (tid < 16 * 16) {
+            const int r = tid >> 4, j = tid & 15;
+            if (j < ad) {
+                float sum = 0.f;
+                float pv[T];
+#pragma unroll
+                for (int tp = 0; tp < T; ++tp) pv[tp] = __uint_as_float((unsigned)__hip_atomic_load(
+                    (const FQL_GAS unsigned*)(P.Vpart + ((size_t)tp * M + row0 + r) * ap + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+                for (int tp = 0; tp < T; ++tp) sum += pv[tp];
+                stg(P.tgt + (size_t)(row0 + r) * ap + j, clip1(ea[r * 32 + j] + (sum + ldg(P.b4 + j)) * inv_steps));
+            }
+        }
+    }
+}
+
 // sample_actions / flow_actions input assembly: X[n_pad, inp] = concat(obs, noise[, t=0])
 struct AssembleArgs {
     const float *obs, *noise;  // noise null => RNG keyed by (key, seed)
