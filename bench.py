@@ -72,7 +72,8 @@ def main():
             raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dp = bool(os.environ.get('FQL_BENCH_FORCE_DP'))  # exercise the RCCL path on one GPU (torchrun --nproc-per-node 1)
+    if world > 1 or force_dp:
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
@@ -83,7 +84,7 @@ def main():
     agent = fql_amd.FQLAgent.create(rank, ds['observations'][:1], ds['actions'][:1], cfg)
     agent.upload_dataset(ds)
     stream = None if os.environ.get('FQL_BENCH_OWN_STREAM') else torch.cuda.current_stream().cuda_stream
-    dp = DataParallelFQL(agent) if world > 1 else None
+    dp = DataParallelFQL(agent) if dist is not None else None
     lo, hi = shard_range(args.rows, rank, world)
 
     def step():

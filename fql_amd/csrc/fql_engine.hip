@@ -122,6 +122,9 @@ struct Launch {
     Op op;                  // arg-struct kernels
     int lane = 0;
     bool tmt2 = false, kbig = false, euler = false;
+    bool side = false;           // merged gemm64 + wgrad + lnbwd launch
+    void *table_w = nullptr, *table_l = nullptr;
+    int n_w = 0, n_l = 0, tile_w = 0, tile_l = 0;
     std::vector<int> waits;      // launches of the OTHER lane that must have completed
     bool record_after = false;   // some launch of the other lane waits on this one
     hipEvent_t ev = nullptr;
@@ -621,7 +624,7 @@ struct fql_engine {
                 op.writes = {w.dW, w.db};
                 // weight gradients feed nothing but the optimizer: background lane
                 const int keep = emit_lane;
-                static const bool wlane = getenv("FQL_NO_WLANE") == nullptr;
+                static const bool wlane = getenv("FQL_WLANE") != nullptr;  // (a separate wgrad lane is worse than sharing launches)
                 if (wlane) emit_lane = 2;
                 push(pr, op);
                 emit_lane = keep;
@@ -745,6 +748,68 @@ struct fql_engine {
                 for (int oi = 0; oi < (int)pr.ops.size(); ++oi) {
                     const Op& op = pr.ops[oi];
                     if (op.level == lv && op.type == ty && op.lane == lane) sel.push_back(&op);
+                }
+                static const bool merge_side = getenv("FQL_NO_SIDE") == nullptr;
+                if (merge_side && (ty == OP_WGRAD || ty == OP_LNBWD)) continue;  // folded into the OP_GEMM64 iteration
+                if (merge_side && ty == OP_GEMM64) {
+                    std::vector<const Op*> selw, sell;
+                    for (const Op& op : pr.ops) {
+                        if (op.level != lv || op.lane != lane) continue;
+                        if (op.type == OP_WGRAD) selw.push_back(&op);
+                        if (op.type == OP_LNBWD) sell.push_back(&op);
+                    }
+                    if (sel.empty() && selw.empty() && sell.empty()) continue;
+                    if (lane >= 1) pr.two_lanes = true;
+                    pr.lane_used[lane] = true;
+                    Launch L;
+                    L.type = OP_GEMM64;
+                    L.side = true;
+                    L.lane = lane;
+                    const int li = (int)pr.launches.size();
+                    for (const Op* o : sel) launch_of[o - pr.ops.data()] = li;
+                    for (const Op* o : selw) launch_of[o - pr.ops.data()] = li;
+                    for (const Op* o : sell) launch_of[o - pr.ops.data()] = li;
+                    static const int ri = getenv("FQL_G64_RI") ? atoi(getenv("FQL_G64_RI")) : 1;
+                    int tile = 0;
+                    std::vector<GemmTask> tg;
+                    for (const Op* o : sel) {
+                        GemmTask t = o->gemm;
+                        t.wk = 1; t.tmt = ri;
+                        t.ntn = t.N / 64; t.tile0 = tile;
+                        tile += (t.M / (32 * ri)) * t.ntn;
+                        tg.push_back(t);
+                    }
+                    L.tile_w = tile;
+                    std::vector<WgradTask> tw;
+                    int tilew = 0;
+                    for (const Op* o : selw) {
+                        WgradTask t = o->wgrad;
+                        t.ntn = (t.N + 63) / 64; t.tile0 = tilew;
+                        tilew += (t.Kin / 16) * t.ntn;
+                        tw.push_back(t);
+                    }
+                    L.tile_l = L.tile_w + tilew;
+                    std::vector<LnBwdTask> tl;
+                    int tilel = 0;
+                    for (const Op* o : sell) {
+                        LnBwdTask t = o->ln;
+                        t.ntiles_rows = (t.M + 3) / 4; t.tile0 = tilel;
+                        tilel += t.ntiles_rows + (t.dgamma ? t.H / 16 : 0);
+                        tl.push_back(t);
+                    }
+                    L.grid = L.tile_l + tilel;
+                    L.ntasks = (int)tg.size(); L.n_w = (int)tw.size(); L.n_l = (int)tl.size();
+                    L.lds = sizeof(float) * (tg.empty() ? (size_t)FQL_WGRAD_LDS_FLOATS : (size_t)(2 * (32 * ri + 64) * 68 + 256));
+                    auto up = [&](const void* src, size_t bytes) -> void* {
+                        void* d = dalloc(owner, bytes / sizeof(float) + 4);
+                        if (bytes) HIP_CHECK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+                        return d;
+                    };
+                    L.table = up(tg.data(), tg.size() * sizeof(GemmTask));
+                    L.table_w = up(tw.data(), tw.size() * sizeof(WgradTask));
+                    L.table_l = up(tl.data(), tl.size() * sizeof(LnBwdTask));
+                    pr.launches.push_back(L);
+                    continue;
                 }
                 if (sel.empty()) continue;
                 if (lane >= 1) pr.two_lanes = true;
@@ -892,7 +957,11 @@ struct fql_engine {
                     else hipLaunchKernelGGL((fql_gemm16_kernel<false, false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
                     break;
                 case OP_GEMM64:
-                    hipLaunchKernelGGL(fql_gemm64_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
+                    if (L.side)
+                        hipLaunchKernelGGL(fql_side_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks,
+                                           (const WgradTask*)L.table_w, L.n_w, (const LnBwdTask*)L.table_l, L.n_l, L.tile_w, L.tile_l);
+                    else
+                        hipLaunchKernelGGL(fql_gemm64_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
                     break;
                 case OP_WGRAD:
                     hipLaunchKernelGGL(fql_wgrad_kernel, dim3(L.grid), dim3(FQL_THREADS), 0, s, (const WgradTask*)L.table, L.ntasks);

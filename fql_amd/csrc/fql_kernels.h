@@ -622,7 +622,7 @@ __device__ __forceinline__ void gemm64_body(const GemmTask& T, float* lds) {
     float* As = lds;                    // [2][TM][G64_S]
     float* Bs = lds + 2 * TM * G64_S;   // [2][64][G64_S]   ([k][n], or [n][k] when GF_TRANS_B)
     float* part = Bs + 2 * 64 * G64_S;  // [2][TM][2] LN partial sums of the epilogue
-    const int local = blockIdx.x - T.tile0;
+    const int local = (int)blockIdx.x - T.tile0;  // gemm64 tasks always come first in a launch
     const int tm = local / T.ntn, tn = local - tm * T.ntn;
     const int row0 = tm * TM, n0 = tn * 64;
     const int K = T.K;
@@ -830,12 +830,11 @@ __device__ __forceinline__ void wgrad_load_chunk(float (&a)[8], float (&b)[32], 
         for (int t = 0; t < 4; ++t) b[4 * i + t] = (v && t < ntv) ? ldg(zp + i * sz + 16 * t) : 0.f;
     }
 }
-__global__ __launch_bounds__(FQL_THREADS) void fql_wgrad_kernel(const WgradTask* __restrict__ tasks, int ntasks) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 * 4];  // [wave][tile][lane] float4
-    __shared__ float redb[4][64];
-    const int ti = find_task(tasks, ntasks, blockIdx.x);
-    const WgradTask& T = tasks[ti];
-    const int local = blockIdx.x - T.tile0;
+// lds: 4 * 4 * 64 * 4 + 4 * 64 floats.  bid = block index inside the wgrad task space of the launch.
+__device__ __forceinline__ void wgrad_body(const WgradTask& T, int bid, float* lds) {
+    float* red = lds;                    // [wave][tile][lane] float4
+    float (*redb)[64] = reinterpret_cast<float (*)[64]>(lds + 4 * 4 * 64 * 4);
+    const int local = bid - T.tile0;
     const int tk = local / T.ntn, tn = local - tk * T.ntn;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 15, q = lane >> 4;
@@ -889,6 +888,11 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_wgrad_kernel(const WgradTask*
         }
     }
 }
+#define FQL_WGRAD_LDS_FLOATS (4 * 4 * 64 * 4 + 4 * 64)
+__global__ __launch_bounds__(FQL_THREADS) void fql_wgrad_kernel(const WgradTask* __restrict__ tasks, int ntasks) {
+    __shared__ __attribute__((aligned(16))) float lds_w[FQL_WGRAD_LDS_FLOATS];
+    wgrad_body(tasks[find_task(tasks, ntasks, blockIdx.x)], blockIdx.x, lds_w);
+}
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm backward fused with GELU' (critic, utils/networks.py:56-58 reversed):
@@ -905,8 +909,8 @@ __device__ __forceinline__ void gelu_both(float x, float& g, float& dg) {
     dg = 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * du;
 }
 template <bool SYN>  // SYN: dY[m][k] = dq[m] * wq[k] (scalar head), else dY is read from memory
-__device__ __forceinline__ void lnbwd_body(const LnBwdTask& T, float (*red)[16][16]) {
-    const int local = blockIdx.x - T.tile0;
+__device__ __forceinline__ void lnbwd_body(const LnBwdTask& T, int bid, float (*red)[16][16]) {
+    const int local = bid - T.tile0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (local < T.ntiles_rows) {
         const int row = local * 4 + wave;
@@ -986,8 +990,38 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_lnbwd_kernel(const LnBwdTask*
     __shared__ float red[2][16][16];
     const int ti = find_task(tasks, ntasks, blockIdx.x);
     const LnBwdTask& T = tasks[ti];
-    if (T.dq) lnbwd_body<true>(T, red);
-    else lnbwd_body<false>(T, red);
+    if (T.dq) lnbwd_body<true>(T, blockIdx.x, red);
+    else lnbwd_body<false>(T, blockIdx.x, red);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One launch per level of the side lane: gemm64 tiles, then weight-gradient tiles, then LayerNorm-backward tiles.
+// Every kernel boundary costs the whole chip ~3 us of launch / cache-flush time whichever stream it sits on
+// (experiments/multi_chain.hip), so independent work of one level shares a launch even across kernel families.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FQL_THREADS, 2) void fql_side_kernel(const GemmTask* __restrict__ gt, int ngt, const WgradTask* __restrict__ wt,
+                                                                  int nwt, const LnBwdTask* __restrict__ lt, int nlt, int tile_w, int tile_l) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x;
+    if (b < tile_w) {
+        const GemmTask& T = gt[find_task(gt, ngt, b)];
+        if (T.tmt == 1) {
+            if (T.flags & GF_TRANS_B) gemm64_body<true, 1>(T, lds);
+            else gemm64_body<false, 1>(T, lds);
+        } else {
+            if (T.flags & GF_TRANS_B) gemm64_body<true, 2>(T, lds);
+            else gemm64_body<false, 2>(T, lds);
+        }
+    } else if (b < tile_l) {
+        const int bid = b - tile_w;
+        wgrad_body(wt[find_task(wt, nwt, bid)], bid, lds);
+    } else {
+        const int bid = b - tile_l;
+        const LnBwdTask& T = lt[find_task(lt, nlt, bid)];
+        float (*red)[16][16] = reinterpret_cast<float (*)[16][16]>(lds);
+        if (T.dq) lnbwd_body<true>(T, bid, red);
+        else lnbwd_body<false>(T, bid, red);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
