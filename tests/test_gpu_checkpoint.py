@@ -1,0 +1,58 @@
+"""GPU: checkpoint round trip in the reference's state-dict layout (utils/flax_utils.py:162-202) and the opt-in
+persistent Euler-chain kernel against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fql_oracle as O
+from tests.util import assert_info_close, leaf_dict, make_problem, randomize_params
+
+pytestmark = pytest.mark.gpu
+
+
+def test_checkpoint_roundtrip_resumes_bit_identically(tmp_path):
+    import fql_amd
+    from fql_amd import checkpoint
+    od, ad, B = 29, 8, 32
+    cfg, ds, batch, noise = make_problem(od, ad, B, (64, 64, 64, 64), seed=13)
+    a = fql_amd.FQLAgent.create(3, batch['observations'][:1], batch['actions'][:1], cfg)
+    for s in range(3):
+        a.update(batch, noise=O.make_noise(B, ad, 50 + s))
+    sd = checkpoint.to_state_dict(a)
+    # layout of flax.serialization.to_state_dict(FQLAgent)
+    assert set(sd) == {'rng', 'network'} and set(sd['network']) == {'step', 'params', 'opt_state'}
+    assert set(sd['network']['opt_state']) == {'0', '1'} and set(sd['network']['opt_state']['0']) == {'count', 'mu', 'nu'}
+    assert int(sd['network']['step']) == 4 and int(sd['network']['opt_state']['0']['count']) == 3
+    assert sd['network']['params']['modules_critic']['value_net']['Dense_0']['kernel'].shape == (2, od + ad, 64)
+    checkpoint.save_agent(a, str(tmp_path), 7)
+    b = fql_amd.FQLAgent.create(99, batch['observations'][:1], batch['actions'][:1], cfg)
+    b = checkpoint.restore_agent(b, str(tmp_path), 7)
+    for p, x in leaf_dict(a.get_params()).items():
+        np.testing.assert_array_equal(leaf_dict(b.get_params())[p], x, err_msg=p)
+    nz = O.make_noise(B, ad, 77)
+    _, ia = a.update(batch, noise=nz)
+    _, ib = b.update(batch, noise=nz)
+    assert ia == ib                                     # same state, same kernels: bitwise equal infos
+    assert b.get_opt_state()['count'] == 4
+
+
+def test_persistent_euler_chain_matches_oracle():
+    """FQL_PEC=1: the whole Euler chain in one persistent launch (team hand-offs through L2)."""
+    import fql_amd
+    od, ad, B = 29, 8, 256
+    os.environ['FQL_PEC'] = '1'
+    try:
+        cfg, ds, batch, noise = make_problem(od, ad, B, (512, 512, 512, 512), seed=17)
+        agent = fql_amd.FQLAgent.create(0, batch['observations'][:1], batch['actions'][:1], cfg)
+    finally:
+        del os.environ['FQL_PEC']
+    params = randomize_params(agent.get_params(), seed=4, scale=0.05)
+    agent.set_params(params)
+    ref = O.OracleFQL(params, dict(cfg), od, ad, np.float64)
+    for s in range(3):
+        nz = O.make_noise(B, ad, 90 + s)
+        _, ig = agent.update(batch, noise=nz)
+        _, ir = ref.update(batch, nz)
+        assert_info_close(ig, ir, rtol=1e-4, atol=1e-5)
+    assert agent.stats()['launches_per_update'] < 50     # the chain is one launch on this path
