@@ -159,3 +159,31 @@ def test_errors_are_python_exceptions():
         agent.set_params({'modules_critic': {'value_net': {'Dense_0': {'bias': np.zeros(3, np.float32)}}}})
     with pytest.raises(ValueError):
         agent.sample_actions(np.zeros((4, 9), np.float32))
+
+
+def test_config3_cube_shaped_batch_1024():
+    """BASELINE.json configs[2]: cube-single-shaped (obs=40, act=4), alpha=300, batch=1024."""
+    od, ad, B = 40, 4, 1024
+    cfg, ds, batch, noise = make_problem(od, ad, B, (512, 512, 512, 512), seed=51, alpha=300.0)
+    agent = _agent(cfg, batch)
+    params = randomize_params(agent.get_params(), seed=8, scale=0.05)
+    agent.set_params(params)
+    ref = O.OracleFQL(params, dict(cfg), od, ad, np.float32)   # fp32 numpy oracle: ~10 s at this size
+    _, info_u = agent.update(batch, noise=noise)
+    _, info_ru = ref.update(batch, noise)
+    assert_info_close(info_u, info_ru, rtol=2e-4, atol=2e-5)
+    assert agent.stats()['macs_per_update'] == 24227840 * 1024     # SURVEY.md 8d: 48,455,680 FLOP/sample
+
+
+def test_batch_size_switch_keeps_state():
+    od, ad = 11, 5
+    cfg, ds, batch, noise = make_problem(od, ad, 64, (64, 64, 64, 64), seed=61)
+    agent = _agent(cfg, batch)
+    before = leaf_dict(agent.get_params())
+    small = {k: v[:32] for k, v in batch.items()}
+    loss, _ = agent.total_loss(small, noise={k: v[:32] for k, v in noise.items()})   # re-sizes the workspace to 32 rows
+    assert np.isfinite(loss)
+    for p, a in leaf_dict(agent.get_params()).items():
+        np.testing.assert_array_equal(a, before[p], err_msg=p)
+    agent.update(batch, noise=noise)                                                  # and back to 64
+    assert agent.get_opt_state()['count'] == 1
