@@ -623,9 +623,12 @@ struct fql_engine {
                 op.reads = {xin_id, dz};
                 op.writes = {w.dW, w.db};
                 // weight gradients feed nothing but the optimizer: background lane
+                // weight gradients feed nothing but the optimizer: those of a chain that runs on the critical lane are
+                // issued on the side lane so they never sit between two links of that chain
                 const int keep = emit_lane;
                 static const bool wlane = getenv("FQL_WLANE") != nullptr;  // (a separate wgrad lane is worse than sharing launches)
                 if (wlane) emit_lane = 2;
+                else if (emit_lane == 0 && getenv("FQL_NO_WSIDE") == nullptr) emit_lane = 1;
                 push(pr, op);
                 emit_lane = keep;
             }
