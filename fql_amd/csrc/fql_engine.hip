@@ -123,8 +123,8 @@ struct Launch {
     int lane = 0;
     bool tmt2 = false, kbig = false, euler = false;
     bool side = false;           // merged gemm64 + wgrad + lnbwd launch
-    void *table_w = nullptr, *table_l = nullptr;
-    int n_w = 0, n_l = 0, tile_w = 0, tile_l = 0;
+    void *table_w = nullptr, *table_l = nullptr, *table_m = nullptr;
+    int n_w = 0, n_l = 0, tile_w = 0, tile_l = 0, tile_m = 0;
     std::vector<int> waits;      // launches of the OTHER lane that must have completed
     bool record_after = false;   // some launch of the other lane waits on this one
     hipEvent_t ev = nullptr;
@@ -753,15 +753,17 @@ struct fql_engine {
                     if (op.level == lv && op.type == ty && op.lane == lane) sel.push_back(&op);
                 }
                 static const bool merge_side = getenv("FQL_NO_SIDE") == nullptr;
-                if (merge_side && (ty == OP_WGRAD || ty == OP_LNBWD)) continue;  // folded into the OP_GEMM64 iteration
+                if (merge_side && (ty == OP_WGRAD || ty == OP_LNBWD || ty == OP_POSTOS || ty == OP_LOSS_CRITIC || ty == OP_LOSS_Q ||
+                                   ty == OP_LOSS_BC)) continue;  // folded into the OP_GEMM64 iteration
                 if (merge_side && ty == OP_GEMM64) {
-                    std::vector<const Op*> selw, sell;
+                    std::vector<const Op*> selw, sell, selm;
                     for (const Op& op : pr.ops) {
                         if (op.level != lv || op.lane != lane) continue;
                         if (op.type == OP_WGRAD) selw.push_back(&op);
                         if (op.type == OP_LNBWD) sell.push_back(&op);
+                        if (op.type == OP_POSTOS || op.type == OP_LOSS_CRITIC || op.type == OP_LOSS_Q || op.type == OP_LOSS_BC) selm.push_back(&op);
                     }
-                    if (sel.empty() && selw.empty() && sell.empty()) continue;
+                    if (sel.empty() && selw.empty() && sell.empty() && selm.empty()) continue;
                     if (lane >= 1) pr.two_lanes = true;
                     pr.lane_used[lane] = true;
                     Launch L;
@@ -772,6 +774,7 @@ struct fql_engine {
                     for (const Op* o : sel) launch_of[o - pr.ops.data()] = li;
                     for (const Op* o : selw) launch_of[o - pr.ops.data()] = li;
                     for (const Op* o : sell) launch_of[o - pr.ops.data()] = li;
+                    for (const Op* o : selm) launch_of[o - pr.ops.data()] = li;
                     static const int ri = getenv("FQL_G64_RI") ? atoi(getenv("FQL_G64_RI")) : 1;
                     int tile = 0;
                     std::vector<GemmTask> tg;
@@ -800,7 +803,17 @@ struct fql_engine {
                         tilel += t.ntiles_rows + (t.dgamma ? t.H / 16 : 0);
                         tl.push_back(t);
                     }
-                    L.grid = L.tile_l + tilel;
+                    L.tile_m = L.tile_l + tilel;
+                    std::vector<MiscTask> tmisc;
+                    for (const Op* o : selm) {
+                        MiscTask t{};
+                        if (o->type == OP_POSTOS) { t.kind = MISC_POSTOS; t.po = o->postos; }
+                        else if (o->type == OP_LOSS_CRITIC) { t.kind = MISC_LOSS_CRITIC; t.lc = o->lc; }
+                        else if (o->type == OP_LOSS_Q) { t.kind = MISC_LOSS_Q; t.lq = o->lq; }
+                        else { t.kind = MISC_LOSS_BC; t.lb = o->lb; }
+                        tmisc.push_back(t);
+                    }
+                    L.grid = L.tile_m + (int)tmisc.size();
                     L.ntasks = (int)tg.size(); L.n_w = (int)tw.size(); L.n_l = (int)tl.size();
                     L.lds = sizeof(float) * (tg.empty() ? (size_t)FQL_WGRAD_LDS_FLOATS : (size_t)(2 * (32 * ri + 64) * 68 + 256));
                     auto up = [&](const void* src, size_t bytes) -> void* {
@@ -811,6 +824,7 @@ struct fql_engine {
                     L.table = up(tg.data(), tg.size() * sizeof(GemmTask));
                     L.table_w = up(tw.data(), tw.size() * sizeof(WgradTask));
                     L.table_l = up(tl.data(), tl.size() * sizeof(LnBwdTask));
+                    L.table_m = up(tmisc.data(), tmisc.size() * sizeof(MiscTask));
                     pr.launches.push_back(L);
                     continue;
                 }
@@ -962,7 +976,8 @@ struct fql_engine {
                 case OP_GEMM64:
                     if (L.side)
                         hipLaunchKernelGGL(fql_side_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks,
-                                           (const WgradTask*)L.table_w, L.n_w, (const LnBwdTask*)L.table_l, L.n_l, L.tile_w, L.tile_l);
+                                           (const WgradTask*)L.table_w, L.n_w, (const LnBwdTask*)L.table_l, L.n_l, L.tile_w, L.tile_l,
+                                           (const MiscTask*)L.table_m, L.tile_m);
                     else
                         hipLaunchKernelGGL(fql_gemm64_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
                     break;

@@ -995,36 +995,6 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_lnbwd_kernel(const LnBwdTask*
 }
 
 // ------------------------------------------------------------------------------------------------
-// One launch per level of the side lane: gemm64 tiles, then weight-gradient tiles, then LayerNorm-backward tiles.
-// Every kernel boundary costs the whole chip ~3 us of launch / cache-flush time whichever stream it sits on
-// (experiments/multi_chain.hip), so independent work of one level shares a launch even across kernel families.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(FQL_THREADS, 2) void fql_side_kernel(const GemmTask* __restrict__ gt, int ngt, const WgradTask* __restrict__ wt,
-                                                                  int nwt, const LnBwdTask* __restrict__ lt, int nlt, int tile_w, int tile_l) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int b = blockIdx.x;
-    if (b < tile_w) {
-        const GemmTask& T = gt[find_task(gt, ngt, b)];
-        if (T.tmt == 1) {
-            if (T.flags & GF_TRANS_B) gemm64_body<true, 1>(T, lds);
-            else gemm64_body<false, 1>(T, lds);
-        } else {
-            if (T.flags & GF_TRANS_B) gemm64_body<true, 2>(T, lds);
-            else gemm64_body<false, 2>(T, lds);
-        }
-    } else if (b < tile_l) {
-        const int bid = b - tile_w;
-        wgrad_body(wt[find_task(wt, nwt, bid)], bid, lds);
-    } else {
-        const int bid = b - tile_l;
-        const LnBwdTask& T = lt[find_task(lt, nlt, bid)];
-        float (*red)[16][16] = reinterpret_cast<float (*)[16][16]>(lds);
-        if (T.dq) lnbwd_body<true>(T, bid, red);
-        else lnbwd_body<false>(T, bid, red);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // step state + batch assembly
 // ------------------------------------------------------------------------------------------------
 struct DevState {
@@ -1144,8 +1114,7 @@ struct PostOsArgs {
     int B, od, ad, inp_c, ap;
 };
 // agents/fql.py:26 (clip next actions), :69 (clip actor actions), :82-83 (mse metric)
-__global__ __launch_bounds__(FQL_THREADS) void fql_post_onestep_kernel(PostOsArgs P) {
-    __shared__ float sh[4];
+__device__ __forceinline__ void fql_post_onestep_body(const PostOsArgs& P, float* sh) {
     float se = 0.f;
     const int n = P.B * P.ad;
     for (int e = threadIdx.x; e < n; e += FQL_THREADS) {
@@ -1166,8 +1135,7 @@ struct LossCriticArgs {
     float discount;
 };
 // agents/fql.py:28-44
-__global__ __launch_bounds__(FQL_THREADS) void fql_loss_critic_kernel(LossCriticArgs P) {
-    __shared__ float sh[4];
+__device__ __forceinline__ void fql_loss_critic_body(const LossCriticArgs& P, float* sh) {
     float sl = 0.f, sq = 0.f, mx = -INFINITY, mn = INFINITY;
     const float gs = 1.0f / (float)P.B;  // d/dq of mean over 2B of (q-y)^2 = 2 (q-y) / (2B)
     for (int b = threadIdx.x; b < P.B; b += FQL_THREADS) {
@@ -1203,8 +1171,7 @@ struct LossQArgs {
     int B, normalize, want_grad;
 };
 // agents/fql.py:70-76
-__global__ __launch_bounds__(FQL_THREADS) void fql_loss_q_kernel(LossQArgs P) {
-    __shared__ float sh[4];
+__device__ __forceinline__ void fql_loss_q_body(const LossQArgs& P, float* sh) {
     float s = 0.f, sa = 0.f;
     for (int b = threadIdx.x; b < P.B; b += FQL_THREADS) {
         const float q = 0.5f * (P.q2a[(size_t)b * 16] + P.q2b[(size_t)b * 16]);
@@ -1234,8 +1201,7 @@ struct LossBcArgs {
     int B, ad, ap, want_grad;
 };
 // agents/fql.py:58-59
-__global__ __launch_bounds__(FQL_THREADS) void fql_loss_bc_kernel(LossBcArgs P) {
-    __shared__ float sh[4];
+__device__ __forceinline__ void fql_loss_bc_body(const LossBcArgs& P, float* sh) {
     const int n = P.B * P.ad;
     const float gs = 2.0f / (float)n;
     float s = 0.f;
@@ -1259,8 +1225,7 @@ struct LossActorArgs {
     float alpha;
 };
 // agents/fql.py:66 (distill), :69-79 (clip mask on the Q path, total actor loss)
-__global__ __launch_bounds__(FQL_THREADS) void fql_loss_actor_kernel(LossActorArgs P) {
-    __shared__ float sh[4];
+__device__ __forceinline__ void fql_loss_actor_body(const LossActorArgs& P, float* sh) {
     const int n = P.B * P.ad;
     const float gs = P.alpha * 2.0f / (float)n;
     float s = 0.f;
@@ -1285,6 +1250,24 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_loss_actor_kernel(LossActorAr
         P.st->info[4] = P.st->info[5] + P.alpha * distill + P.st->info[7];
     }
 }
+
+__global__ __launch_bounds__(FQL_THREADS) void fql_post_onestep_kernel(PostOsArgs P) { __shared__ float sh[4]; fql_post_onestep_body(P, sh); }
+__global__ __launch_bounds__(FQL_THREADS) void fql_loss_critic_kernel(LossCriticArgs P) { __shared__ float sh[4]; fql_loss_critic_body(P, sh); }
+__global__ __launch_bounds__(FQL_THREADS) void fql_loss_q_kernel(LossQArgs P) { __shared__ float sh[4]; fql_loss_q_body(P, sh); }
+__global__ __launch_bounds__(FQL_THREADS) void fql_loss_bc_kernel(LossBcArgs P) { __shared__ float sh[4]; fql_loss_bc_body(P, sh); }
+__global__ __launch_bounds__(FQL_THREADS) void fql_loss_actor_kernel(LossActorArgs P) { __shared__ float sh[4]; fql_loss_actor_body(P, sh); }
+
+// single-workgroup loss / metric tasks that ride in a side-lane launch
+enum : int { MISC_POSTOS = 0, MISC_LOSS_CRITIC, MISC_LOSS_Q, MISC_LOSS_BC };
+struct MiscTask {
+    int kind;
+    union {
+        PostOsArgs po;
+        LossCriticArgs lc;
+        LossQArgs lq;
+        LossBcArgs lb;
+    };
+};
 
 // ------------------------------------------------------------------------------------------------
 // K10-K12: grad stats + Adam + Polyak in one pass over the trainable arena
@@ -1745,3 +1728,44 @@ __global__ void fql_dataset_add_kernel(float* obs, float* act, float* rew, float
     if (j < ad) act[pos * ad + j] = row[od + j];
     if (j == 0) { rew[pos] = row[od + ad]; mask[pos] = row[od + ad + 1]; }
 }
+
+// ------------------------------------------------------------------------------------------------
+// One launch per level of the side lane: gemm64 tiles, then weight-gradient tiles, then LayerNorm-backward tiles, then
+// the single-workgroup loss / metric tasks of that level.
+// Every kernel boundary costs the whole chip ~3 us of launch / cache-flush time whichever stream it sits on
+// (experiments/multi_chain.hip), so independent work of one level shares a launch even across kernel families.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FQL_THREADS, 2) void fql_side_kernel(const GemmTask* __restrict__ gt, int ngt, const WgradTask* __restrict__ wt,
+                                                                  int nwt, const LnBwdTask* __restrict__ lt, int nlt, int tile_w, int tile_l,
+                                                                  const MiscTask* __restrict__ mt, int tile_m) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x;
+    if (b < tile_w) {
+        const GemmTask& T = gt[find_task(gt, ngt, b)];
+        if (T.tmt == 1) {
+            if (T.flags & GF_TRANS_B) gemm64_body<true, 1>(T, lds);
+            else gemm64_body<false, 1>(T, lds);
+        } else {
+            if (T.flags & GF_TRANS_B) gemm64_body<true, 2>(T, lds);
+            else gemm64_body<false, 2>(T, lds);
+        }
+    } else if (b < tile_l) {
+        const int bid = b - tile_w;
+        wgrad_body(wt[find_task(wt, nwt, bid)], bid, lds);
+    } else if (b < tile_m) {
+        const int bid = b - tile_l;
+        const LnBwdTask& T = lt[find_task(lt, nlt, bid)];
+        float (*red)[16][16] = reinterpret_cast<float (*)[16][16]>(lds);
+        if (T.dq) lnbwd_body<true>(T, bid, red);
+        else lnbwd_body<false>(T, bid, red);
+    } else {
+        const MiscTask& T = mt[b - tile_m];
+        switch (T.kind) {
+            case MISC_POSTOS: fql_post_onestep_body(T.po, lds); break;
+            case MISC_LOSS_CRITIC: fql_loss_critic_body(T.lc, lds); break;
+            case MISC_LOSS_Q: fql_loss_q_body(T.lq, lds); break;
+            default: fql_loss_bc_body(T.lb, lds); break;
+        }
+    }
+}
+
