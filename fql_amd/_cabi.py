@@ -54,6 +54,9 @@ SYMBOLS = {
     'fql_update': (_I, [_VP] + _BATCH + [C.POINTER(FqlNoise), _VP, _VP]),
     'fql_update_begin': (_I, [_VP] + _BATCH + [C.POINTER(FqlNoise), _VP]),
     'fql_update_end': (_I, [_VP, _VP, _VP]),
+    'fql_update_begin_split': (_I, [_VP] + _BATCH + [C.POINTER(FqlNoise), _VP, _VP]),
+    'fql_update_from_dataset_begin_split': (_I, [_VP, _VP, _I, _I64, _I64, C.POINTER(FqlNoise), _VP, _VP]),
+    'fql_grad_buckets': (_I, [_VP, C.POINTER(_SZ), C.POINTER(_SZ)]),
     'fql_grad_buffer': (_I, [_VP, C.POINTER(_VP), C.POINTER(_SZ)]),
     'fql_set_grad_scale': (_I, [_VP, _F]),
     'fql_total_loss': (_I, [_VP] + _BATCH + [C.POINTER(FqlNoise), C.POINTER(_F), C.POINTER(_F), _VP]),

@@ -302,6 +302,34 @@ class FQLAgent:
     def update_end(self, stream=None):
         self._check(self._lib.fql_update_end(self._h, None, stream))
 
+    def grad_buckets(self):
+        """[(offset, length)] x 2 in floats inside grad_buffer(), or None if the engine has no split program."""
+        off, ln = (C.c_size_t * 2)(), (C.c_size_t * 2)()
+        rc = self._lib.fql_grad_buckets(self._h, off, ln)
+        if rc != 0:
+            return None
+        return [(int(off[0]), int(ln[0])), (int(off[1]), int(ln[1]))]
+
+    def update_begin_split(self, stream0, stream1, batch=None, noise=None, idxs=None, shard=(0, 0), batch_size=None):
+        """fql_update_begin_split / fql_update_from_dataset_begin_split: lane 0 on stream0, lane 1 on stream1."""
+        if batch is not None:
+            B, args = self._batch_args(batch)
+            self._ensure_batch(B)
+            nz, nargs = self._noise_args(noise, B)
+            self._check(self._lib.fql_update_begin_split(self._h, *[a.ptr for a in args], B, C.byref(nz) if nz else None,
+                                                         stream0, stream1))
+            self._keep = (args, nargs)
+        else:
+            B = int(batch_size or self.config['batch_size'])
+            self._ensure_batch(B)
+            nz, nargs = self._noise_args(noise, B)
+            ip, keep = None, None
+            if idxs is not None:
+                keep = np.ascontiguousarray(idxs, dtype=np.int64); ip = keep.ctypes.data
+            self._check(self._lib.fql_update_from_dataset_begin_split(self._h, ip, B, int(shard[0]), int(shard[1]),
+                                                                      C.byref(nz) if nz else None, stream0, stream1))
+            self._keep = (keep, nargs)
+
     def grad_buffer(self):
         """(device pointer, number of floats) of the flat trainable-gradient buffer."""
         p, n = C.c_void_p(), C.c_size_t()

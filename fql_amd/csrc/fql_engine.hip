@@ -191,12 +191,20 @@ struct fql_engine {
     float *vel = nullptr, *w_rew = nullptr, *w_mask = nullptr, *w_act = nullptr, *tgt = nullptr;
     float *X_e0 = nullptr, *C0 = nullptr, *Abuf[2] = {nullptr, nullptr}, *Vpart = nullptr;  // fused Euler chain
     bool fused_euler = false, use_pec = false;
+    bool split_build = false;   // building the data-parallel program: lane 1 must not depend on lane 0's backward
+    bool split_ok = false;
     int vp_tiles = 0;
     unsigned* pec_cnt = nullptr;   // [teams][3 flow_steps] arrival counters + 1 error word at the end
     size_t pec_cnt_bytes = 0;
     int num_cus = 0;
     PassBuf p_os, p_os_bwd, p_bc, p_eu, p_c1[2], p_c2[2], p_ct[2];
     Program prog_fwdbwd, prog_opt, prog_loss;
+    // data-parallel variant: the same update as three single-lane graphs (lane 0 before / after it needs lane 1, lane 1)
+    // so the gradient bucket of lane 1 can be all-reduced while lane 0 is still running
+    Program prog_split;
+    hipGraphExec_t split_exec[4] = {nullptr, nullptr, nullptr, nullptr};  // A0 (prep), B (lane 1), A1, A2
+    hipGraph_t split_graph[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
     bool began = false;
 
     // dataset
@@ -628,7 +636,7 @@ struct fql_engine {
                 const int keep = emit_lane;
                 static const bool wlane = getenv("FQL_WLANE") != nullptr;  // (a separate wgrad lane is worse than sharing launches)
                 if (wlane) emit_lane = 2;
-                else if (emit_lane == 0 && getenv("FQL_NO_WSIDE") == nullptr) emit_lane = 1;
+                else if (emit_lane == 0 && !split_build && getenv("FQL_NO_WSIDE") == nullptr) emit_lane = 1;
                 push(pr, op);
                 emit_lane = keep;
             }
@@ -1059,6 +1067,67 @@ struct fql_engine {
         HIP_CHECK(hipGraphInstantiate(&pr.exec, pr.graph, nullptr, nullptr, 0));
     }
 
+    // one graph per segment: seg 0 = lane-0 launches up to the last one lane 1 waits on, seg 1 = lane 1, seg 2 = lane 0 up to
+    // its first wait on lane 1, seg 3 = the rest of lane 0.  Returns false if the program does not have that shape.
+    bool capture_split(Program& pr) {
+        int last_needed_by_lane1 = -1, first_lane0_wait = -1;
+        for (int li = 0; li < (int)pr.launches.size(); ++li) {
+            const Launch& L = pr.launches[li];
+            if (L.lane > 1) return false;
+            for (int w : L.waits) {
+                if (L.lane == 1) last_needed_by_lane1 = std::max(last_needed_by_lane1, w);
+                if (L.lane == 0 && first_lane0_wait < 0) first_lane0_wait = li;
+            }
+        }
+        if (last_needed_by_lane1 < 0 || first_lane0_wait < 0 || first_lane0_wait <= last_needed_by_lane1) return false;
+        auto seg_of = [&](int li) {
+            const Launch& L = pr.launches[li];
+            if (L.lane == 1) return 1;
+            if (li <= last_needed_by_lane1) return 0;
+            return li < first_lane0_wait ? 2 : 3;
+        };
+        for (int seg = 0; seg < 4; ++seg) {
+            Program sub;
+            for (int li = 0; li < (int)pr.launches.size(); ++li)
+                if (seg_of(li) == seg) { Launch L = pr.launches[li]; L.waits.clear(); L.record_after = false; L.ev = nullptr; L.lane = 0; sub.launches.push_back(L); }
+            if (sub.launches.empty()) return false;
+            HIP_CHECK(hipStreamSynchronize(stream));
+            HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            try {
+                run_launches(sub, stream, false);
+            } catch (...) {
+                hipGraph_t g = nullptr;
+                hipStreamEndCapture(stream, &g);
+                if (g) hipGraphDestroy(g);
+                throw;
+            }
+            HIP_CHECK(hipStreamEndCapture(stream, &split_graph[seg]));
+            HIP_CHECK(hipGraphInstantiate(&split_exec[seg], split_graph[seg], nullptr, nullptr, 0));
+        }
+        if (!ev_a) HIP_CHECK(hipEventCreateWithFlags(&ev_a, hipEventDisableTiming));
+        if (!ev_b) HIP_CHECK(hipEventCreateWithFlags(&ev_b, hipEventDisableTiming));
+        return true;
+    }
+    void free_split() {
+        for (int i = 0; i < 4; ++i) {
+            if (split_exec[i]) { hipGraphExecDestroy(split_exec[i]); split_exec[i] = nullptr; }
+            if (split_graph[i]) { hipGraphDestroy(split_graph[i]); split_graph[i] = nullptr; }
+        }
+        split_ok = false;
+    }
+    // enqueue the split update: s0 carries lane 0, s1 lane 1; on return s1 holds everything bucket 0 of the gradient
+    // buffer depends on, s0 everything bucket 1 depends on
+    void launch_split(hipStream_t s0, hipStream_t s1) {
+        HIP_CHECK(hipGraphLaunch(split_exec[0], s0));
+        HIP_CHECK(hipEventRecord(ev_a, s0));
+        HIP_CHECK(hipStreamWaitEvent(s1, ev_a, 0));
+        HIP_CHECK(hipGraphLaunch(split_exec[1], s1));
+        HIP_CHECK(hipEventRecord(ev_b, s1));
+        HIP_CHECK(hipGraphLaunch(split_exec[2], s0));
+        HIP_CHECK(hipStreamWaitEvent(s0, ev_b, 0));
+        HIP_CHECK(hipGraphLaunch(split_exec[3], s0));
+    }
+
     void free_program(Program& pr) {
         if (pr.exec) hipGraphExecDestroy(pr.exec);
         if (pr.graph) hipGraphDestroy(pr.graph);
@@ -1215,6 +1284,8 @@ struct fql_engine {
         free_program(prog_fwdbwd);
         free_program(prog_opt);
         free_program(prog_loss);
+        free_program(prog_split);
+        free_split();
         for (void* p : ws_allocs) hipFree(p);
         ws_allocs.clear();
     }
@@ -1285,6 +1356,13 @@ struct fql_engine {
         build_step_program(prog_loss, false);
         schedule(prog_fwdbwd, W); schedule(prog_opt, W); schedule(prog_loss, W);
         capture(prog_fwdbwd); capture(prog_opt); capture(prog_loss);
+        if (getenv("FQL_NO_SPLIT") == nullptr) {
+            split_build = true;
+            build_step_program(prog_split, true);
+            split_build = false;
+            schedule(prog_split, W);
+            split_ok = capture_split(prog_split);
+        }
         launches_per_update = (int64_t)prog_fwdbwd.launches.size() + (int64_t)prog_opt.launches.size();
         src_valid = false;
     }
@@ -1634,7 +1712,9 @@ static hipStream_t pick(fql_handle h, void* s) { return s ? (hipStream_t)s : h->
 
 static void run_program(fql_handle h, Program& pr, hipStream_t s) {
     static const bool no_graph = getenv("FQL_NO_GRAPH") != nullptr;
+    static const bool split_default = getenv("FQL_SPLIT_DEFAULT") != nullptr;  // experiment: host-launched lane graphs
     if (no_graph) h->run_launches(pr, s);
+    else if (split_default && &pr == &h->prog_fwdbwd && h->split_ok && s != h->stream2) h->launch_split(s, h->stream2);
     else HIP_CHECK(hipGraphLaunch(pr.exec, s));
 }
 
@@ -1760,6 +1840,33 @@ int fql_update_from_dataset_begin(fql_handle h, const int64_t* idx, int batch_si
         run_program(h, h->prog_fwdbwd, s);
         h->began = true;
     });
+}
+int fql_update_from_dataset_begin_split(fql_handle h, const int64_t* idx, int batch_size, int64_t lo, int64_t hi,
+                                        const fql_noise* noise, void* stream0, void* stream1) {
+    if (!h) return FQL_E_INVALID;
+    if (!h->split_ok || !stream0 || !stream1 || stream0 == stream1) { h->err = "split update unavailable (needs two distinct streams and a two-lane program)"; return FQL_E_STATE; }
+    FQL_TRY(h, {
+        h->source_from_dataset(idx, batch_size, lo, hi, noise, (hipStream_t)stream0);
+        h->launch_split((hipStream_t)stream0, (hipStream_t)stream1);
+        h->began = true;
+    });
+}
+int fql_update_begin_split(fql_handle h, const float* obs, const float* act, const float* rew, const float* mask, const float* nobs,
+                           int batch_size, const fql_noise* noise, void* stream0, void* stream1) {
+    if (!h) return FQL_E_INVALID;
+    if (!h->split_ok || !stream0 || !stream1 || stream0 == stream1) { h->err = "split update unavailable (needs two distinct streams and a two-lane program)"; return FQL_E_STATE; }
+    FQL_TRY(h, {
+        h->source_from_batch(obs, act, rew, mask, nobs, batch_size, noise, 1, (hipStream_t)stream0);
+        h->launch_split((hipStream_t)stream0, (hipStream_t)stream1);
+        h->began = true;
+    });
+}
+int fql_grad_buckets(fql_handle h, size_t offsets[2], size_t lengths[2]) {
+    if (!h || !offsets || !lengths) return FQL_E_INVALID;
+    // bucket 0: both critic members + the BC flow actor (all produced on lane 1); bucket 1: the one-step actor (lane 0's tail)
+    offsets[0] = 0; lengths[0] = h->nets[NET_OS].off;
+    offsets[1] = h->nets[NET_OS].off; lengths[1] = h->n_train - h->nets[NET_OS].off;
+    return h->split_ok ? FQL_OK : FQL_E_STATE;
 }
 int fql_update_from_dataset(fql_handle h, const int64_t* idx, int batch_size, int64_t lo, int64_t hi, const fql_noise* noise,
                             float* info13, void* stream) {

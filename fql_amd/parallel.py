@@ -50,7 +50,7 @@ def tree_unflatten(items):
 class DataParallelFQL:
     """Wraps an FQLAgent whose engine lives on this rank's GPU."""
 
-    def __init__(self, agent, process_group=None):
+    def __init__(self, agent, process_group=None, overlap=True):
         import torch
         import torch.distributed as dist
         self.agent = agent
@@ -62,6 +62,13 @@ class DataParallelFQL:
         self.grads = torch.as_tensor(_DevView(ptr, n), device=torch.device('cuda', torch.cuda.current_device()))
         assert self.grads.data_ptr() == ptr and self.grads.numel() == n
         agent.set_grad_scale(1.0 / self.world)
+        # overlapped mode: the engine enqueues lane 1 (critics, BC flow) and lane 0 (Euler chain, one-step actor) on two
+        # streams; the lane-1 gradient bucket (3/4 of the bytes) is all-reduced while lane 0 is still running
+        self.buckets = agent.grad_buckets() if overlap else None
+        if self.buckets is not None:
+            self.side_stream = torch.cuda.Stream()
+            (o0, n0), (o1, n1) = self.buckets
+            self.g0, self.g1 = self.grads[o0:o0 + n0], self.grads[o1:o1 + n1]
         self.broadcast_params()
 
     def broadcast_params(self):
@@ -82,15 +89,34 @@ class DataParallelFQL:
     def update_from_dataset(self, n_rows, batch_size=None, idxs=None, noise=None):
         """One synchronous data-parallel step; indices are drawn from this rank's shard."""
         import torch
-        st = torch.cuda.current_stream().cuda_stream
         lo, hi = shard_range(n_rows, self.rank, self.world)
+        if self.buckets is not None:
+            self._overlapped(lambda s0, s1: self.agent.update_begin_split(s0, s1, idxs=idxs, shard=(lo, hi), batch_size=batch_size, noise=noise))
+            return
+        st = torch.cuda.current_stream().cuda_stream
         self.agent.update_begin(idxs=idxs, shard=(lo, hi), batch_size=batch_size, noise=noise, stream=st)
         if self.world > 1:
             self.dist.all_reduce(self.grads, op=self.dist.ReduceOp.SUM, group=self.pg)
         self.agent.update_end(stream=st)
 
+    def _overlapped(self, begin):
+        import torch
+        main = torch.cuda.current_stream()
+        side = self.side_stream
+        side.wait_stream(main)                       # lane 1 must not start before earlier work on the main stream
+        begin(main.cuda_stream, side.cuda_stream)
+        if self.world > 1:
+            with torch.cuda.stream(side):            # bucket 0 follows lane 1; overlaps the Euler chain on `main`
+                self.dist.all_reduce(self.g0, op=self.dist.ReduceOp.SUM, group=self.pg)
+            self.dist.all_reduce(self.g1, op=self.dist.ReduceOp.SUM, group=self.pg)
+        main.wait_stream(side)
+        self.agent.update_end(stream=main.cuda_stream)
+
     def update(self, batch, noise=None):
         import torch
+        if self.buckets is not None:
+            self._overlapped(lambda s0, s1: self.agent.update_begin_split(s0, s1, batch=batch, noise=noise))
+            return
         st = torch.cuda.current_stream().cuda_stream
         self.agent.update_begin(batch=batch, noise=noise, stream=st)
         if self.world > 1:

@@ -130,6 +130,18 @@ int fql_update_begin(fql_handle h, const float* observations, const float* actio
                      const float* masks, const float* next_observations, int batch_size,
                      const fql_noise* noise, void* stream);
 int fql_update_end(fql_handle h, float* info13, void* stream);
+/* Overlapped variant of fql_update_begin for data-parallel runs: the same update enqueued as single-lane graphs on TWO
+ * streams.  When the call returns, everything gradient bucket 0 (fql_grad_buckets: both critic members + the BC flow
+ * actor) depends on is on `stream1`, everything bucket 1 (the one-step actor) depends on is on `stream0`: all-reduce
+ * bucket 0 on stream1 while stream0 still runs the Euler chain, bucket 1 on stream0, make stream0 wait for stream1,
+ * then fql_update_end(stream0).  Returns FQL_E_STATE if the engine has no two-lane program (then use fql_update_begin). */
+int fql_update_begin_split(fql_handle h, const float* observations, const float* actions, const float* rewards,
+                           const float* masks, const float* next_observations, int batch_size,
+                           const fql_noise* noise, void* stream0, void* stream1);
+int fql_update_from_dataset_begin_split(fql_handle h, const int64_t* idx, int batch_size, int64_t lo, int64_t hi,
+                                        const fql_noise* noise, void* stream0, void* stream1);
+/* offsets / lengths (in floats) of the two gradient buckets inside the buffer fql_grad_buffer returns */
+int fql_grad_buckets(fql_handle h, size_t offsets[2], size_t lengths[2]);
 int fql_grad_buffer(fql_handle h, void** device_ptr, size_t* num_floats);
 int fql_set_grad_scale(fql_handle h, float scale);
 

@@ -96,3 +96,32 @@ def test_replay_ring_insert():
     # utils/datasets.py:489-491 verbatim: pointer = (pointer + 1) % max_size; size = max(pointer, size).
     # 6 -> 7 -> wraps to pointer 0 (size stays 7, the reference never reports max_size after a wrap) -> 1.
     assert a.dataset_size() == (7, 1)
+
+
+def test_split_lane_update_matches_plain_update():
+    """fql_update_begin_split (lane graphs on two streams, bucketed gradients) must give the same step as fql_update."""
+    import fql_amd
+    od, ad, B = 29, 8, 64
+    cfg, ds, batch, noise = make_problem(od, ad, B, (64, 64, 64, 64), seed=23)
+    a = fql_amd.FQLAgent.create(0, batch['observations'][:1], batch['actions'][:1], cfg)
+    b = fql_amd.FQLAgent.create(0, batch['observations'][:1], batch['actions'][:1], cfg)
+    b.set_params(a.get_params())
+    buckets = b.grad_buckets()
+    assert buckets is not None and buckets[0][0] == 0 and buckets[0][1] == buckets[1][0]
+    ptr, n = b.grad_buffer()
+    assert buckets[1][0] + buckets[1][1] == n
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+    for step in range(3):
+        nz = O.make_noise(B, ad, 40 + step)
+        a.update(batch, noise=nz)
+        torch.cuda.synchronize()
+        b.update_begin_split(s0.cuda_stream, s1.cuda_stream, batch=batch, noise=nz)
+        s0.wait_stream(s1)
+        b.update_end(stream=s0.cuda_stream)
+        torch.cuda.synchronize()
+        ia, ib = a.read_info(), b.read_info()
+        for k in ia:
+            assert abs(ia[k] - ib[k]) <= 1e-6 * max(1.0, abs(ia[k])), (step, k, ia[k], ib[k])
+    pa, pb = (dict(O.tree_leaves_with_path(x.get_params())) for x in (a, b))
+    for p in pa:
+        np.testing.assert_allclose(pb[p], pa[p], rtol=0, atol=1e-7, err_msg=p)
