@@ -4,7 +4,8 @@
 """
 from .agent import FQLAgent, INFO_KEYS, NOISE_KEYS
 from .config import get_config
+from .datasets import Dataset, ReplayBuffer
 
 agents = dict(fql=FQLAgent)
 
-__all__ = ['FQLAgent', 'get_config', 'agents', 'INFO_KEYS', 'NOISE_KEYS']
+__all__ = ['FQLAgent', 'get_config', 'agents', 'INFO_KEYS', 'NOISE_KEYS', 'Dataset', 'ReplayBuffer']

@@ -1581,8 +1581,15 @@ int fql_create(const fql_config* cfg, uint64_t seed, fql_handle* out) {
         }
         // (stream priorities were tried for the lanes: no gain with two streams, a 4x slowdown with three)
         h->num_cus = prop.multiProcessorCount;
+        if (const char* cm = getenv("FQL_CUMASK")) {  // experiment: disjoint CU sets for the two lanes (host-launched lane graphs)
+            const uint32_t m0 = (uint32_t)strtoul(cm, nullptr, 16);
+            std::vector<uint32_t> a(8, m0), b(8, ~m0);
+            HIP_CHECK(hipExtStreamCreateWithCUMask(&h->stream, 8, a.data()));
+            HIP_CHECK(hipExtStreamCreateWithCUMask(&h->stream2, 8, b.data()));
+        } else {
         HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+        }
         HIP_CHECK(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
         HIP_CHECK(hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking));
         h->build_nets();

@@ -125,3 +125,26 @@ def test_split_lane_update_matches_plain_update():
     pa, pb = (dict(O.tree_leaves_with_path(x.get_params())) for x in (a, b))
     for p in pa:
         np.testing.assert_allclose(pb[p], pa[p], rtol=0, atol=1e-7, err_msg=p)
+
+
+def test_dataset_mirror_attached_to_engine():
+    """fql_amd.datasets.ReplayBuffer.attach: host ring and device ring stay in step; sampling by explicit idxs on the
+    device equals update(ds.sample(idxs)) on the host path."""
+    import fql_amd
+    from fql_amd.datasets import ReplayBuffer
+    od, ad, B = 5, 2, 16
+    cfg = fql_amd.get_config(); cfg.update(actor_hidden_dims=(32, 32), value_hidden_dims=(32, 32), batch_size=B, alpha=10.0)
+    init = O.make_synthetic_dataset(40, od, ad, seed=3)
+    a = fql_amd.FQLAgent.create(0, init['observations'][:1], init['actions'][:1], cfg)
+    b = fql_amd.FQLAgent.create(0, init['observations'][:1], init['actions'][:1], cfg)
+    b.set_params(a.get_params())
+    rb = ReplayBuffer.create_from_initial_dataset(init, size=48).attach(a)
+    extra = O.make_synthetic_dataset(12, od, ad, seed=4)
+    for i in range(12):                                    # wraps the 48-row ring
+        rb.add_transition({k: v[i] for k, v in extra.items()})
+    assert a.dataset_size() == (rb.size, rb.pointer)
+    idx = np.random.default_rng(0).integers(0, rb.size, size=B)
+    nz = O.make_noise(B, ad, 5)
+    a.update_from_dataset(B, idxs=idx, noise=nz)
+    b.update(rb.sample(B, idxs=idx), noise=nz)
+    assert a.read_info() == b.read_info()
