@@ -19,7 +19,7 @@ from typing import Any, Dict, Optional
 
 import numpy as np
 
-from . import _cabi
+from . import _cabi, jax_prng
 from .config import ConfigDict, get_config
 
 INFO_KEYS = (
@@ -86,6 +86,9 @@ class FQLAgent:
         self._seed = seed
         self._keep = []
         self._sample_calls = 0
+        # agents/fql.py:189-190: rng = PRNGKey(seed); rng, init_rng = split(rng, 2).  Only used when config['rng'] ==
+        # 'jax' (noise drawn on the host with the reference's key derivation) or when a caller passes JAX keys.
+        self.rng = jax_prng.split(jax_prng.PRNGKey(seed), 2)[0]
 
     # -- construction ---------------------------------------------------------------------
     @classmethod
@@ -181,6 +184,8 @@ class FQLAgent:
         tensors explicitly (parity runs); by default they come from the engine's device RNG."""
         B, args = self._batch_args(batch)
         self._ensure_batch(B)
+        if noise is None and self.config.get('rng') == 'jax':
+            self.rng, noise = jax_prng.fql_update_noise(self.rng, B, self.config['action_dim'])
         nz, nargs = self._noise_args(noise, B)
         stream = self._stream(args + nargs)
         self._check(self._lib.fql_update(self._h, *[a.ptr for a in args], B, C.byref(nz) if nz else None, None, stream))
@@ -199,6 +204,8 @@ class FQLAgent:
             raise NotImplementedError('total_loss with traced grad_params is jax.grad plumbing; use update()')
         B, args = self._batch_args(batch)
         self._ensure_batch(B)
+        if noise is None and (rng is not None or self.config.get('rng') == 'jax'):
+            noise = jax_prng.fql_total_loss_noise(self.rng if rng is None else rng, B, self.config['action_dim'])
         nz, nargs = self._noise_args(noise, B)
         loss = C.c_float()
         info = (C.c_float * 10)()
@@ -220,6 +227,9 @@ class FQLAgent:
         od, ad = self.config['ob_dims'][0], self.config['action_dim']
         is_torch = hasattr(observations, 'data_ptr')
         lead = tuple(observations.shape[:-1])
+        if not flow and noises is None and seed is not None and np.ndim(seed) == 1 and np.size(seed) == 2:
+            # a JAX key (what main.py:225 / utils/evaluation.py:98-101 pass): draw exactly the noise the reference draws
+            noises = jax_prng.sample_actions_noise(np.asarray(seed), lead, ad)
         if int(observations.shape[-1]) != od:
             raise ValueError(f'observations last dim must be {od}, got {tuple(observations.shape)}')
         n = int(np.prod(lead)) if lead else 1

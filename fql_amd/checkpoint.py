@@ -26,7 +26,7 @@ import numpy as np
 def to_state_dict(agent) -> dict:
     """flax.serialization.to_state_dict(agent) for the engine-backed FQLAgent."""
     opt = agent.get_opt_state()
-    rng = np.array([(agent._seed >> 32) & 0xFFFFFFFF, agent._seed & 0xFFFFFFFF], dtype=np.uint32)
+    rng = np.asarray(getattr(agent, 'rng', [(agent._seed >> 32) & 0xFFFFFFFF, agent._seed & 0xFFFFFFFF]), dtype=np.uint32)
     return {
         'rng': rng,
         'network': {
@@ -47,6 +47,7 @@ def from_state_dict(agent, state: dict):
     if 'rng' in state and state['rng'] is not None:
         r = np.asarray(state['rng']).astype(np.uint64).reshape(-1)
         if r.size >= 2:
+            agent.rng = r[:2].astype(np.uint32)
             agent._seed = int((int(r[0]) << 32) | int(r[1]))
     return agent
 

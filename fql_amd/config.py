@@ -32,4 +32,5 @@ def get_config():
         flow_steps=10,
         normalize_q_loss=False,
         encoder=None,
+        rng='engine',  # not a reference key: 'engine' = device Philox noise; 'jax' = host threefry, reference key derivation
     )

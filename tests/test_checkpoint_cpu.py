@@ -15,6 +15,7 @@ class FakeAgent:
         self.mu = O.tree_map(lambda a: a * 0.1, params)
         self.nu = O.tree_map(lambda a: a * a, params)
         self.count, self.step, self._seed = 5, 6, (7 << 32) | 9
+        self.rng = np.array([7, 9], dtype=np.uint32)
 
     def get_params(self):
         return self.p

@@ -56,3 +56,27 @@ def test_persistent_euler_chain_matches_oracle():
         _, ir = ref.update(batch, nz)
         assert_info_close(ig, ir, rtol=1e-4, atol=1e-5)
     assert agent.stats()['launches_per_update'] < 50     # the chain is one launch on this path
+
+
+def test_jax_key_paths_match_oracle_with_host_threefry_noise():
+    """config['rng']='jax': update() draws its noise with the reference's key derivation; sample_actions(seed=key)
+    with a JAX key draws the reference's noise.  Checked against the oracle fed the same host-generated tensors."""
+    import fql_amd
+    from fql_amd import jax_prng as J
+    od, ad, B = 29, 8, 32
+    cfg, ds, batch, _ = make_problem(od, ad, B, (64, 64, 64, 64), seed=29)
+    cfg['rng'] = 'jax'
+    agent = fql_amd.FQLAgent.create(5, batch['observations'][:1], batch['actions'][:1], cfg)
+    np.testing.assert_array_equal(agent.rng, J.split(J.PRNGKey(5), 2)[0])           # agents/fql.py:189-190
+    ref = O.OracleFQL(agent.get_params(), {k: v for k, v in cfg.items() if k != 'rng'}, od, ad, np.float64)
+    rng = agent.rng
+    for _ in range(2):
+        rng, nz = J.fql_update_noise(rng, B, ad)
+        _, ig = agent.update(batch)
+        _, ir = ref.update(batch, nz)
+        assert_info_close(ig, ir, rtol=1e-4, atol=1e-5)
+    np.testing.assert_array_equal(agent.rng, rng)
+    key = np.array([123, 456], dtype=np.uint32)
+    got = agent.sample_actions(batch['observations'], seed=key)
+    want = ref.sample_actions(batch['observations'], J.sample_actions_noise(key, (B,), ad))
+    np.testing.assert_allclose(got, want, atol=1e-5)
