@@ -30,6 +30,7 @@ int main(int argc, char** argv) {
         t.B = W + (size_t)((mode & 2) ? 0 : i) * K * N; t.ldb = N; t.bias = b; t.M = M; t.N = N; t.K = K;
         t.flags = GF_BIAS | GF_GELU; t.aux = (float*)stamps; t.wk = wk; t.ntn = (N / 16 + (4 / wk) - 1) / (4 / wk); t.tile0 = 0;
         t.tmt = tmt; grid = (M / (16 * tmt)) * t.ntn;
+        if (mode & 4) { t.flags |= GF_TRANS_B; t.ldb = K; }  // B read as W^T [N][K]: 16-byte fragment loads
         h[i] = t;
     }
     CK(hipMemcpy(tb, h.data(), 8 * sizeof(GemmTask), hipMemcpyHostToDevice));

@@ -62,6 +62,8 @@ class DataParallelFQL:
         self.grads = torch.as_tensor(_DevView(ptr, n), device=torch.device('cuda', torch.cuda.current_device()))
         assert self.grads.data_ptr() == ptr and self.grads.numel() == n
         agent.set_grad_scale(1.0 / self.world)
+        import os
+        self.always_reduce = bool(os.environ.get('FQL_DP_ALWAYS_REDUCE'))  # issue the collectives even at world size 1 (testing)
         # overlapped mode: the engine enqueues lane 1 (critics, BC flow) and lane 0 (Euler chain, one-step actor) on two
         # streams; the lane-1 gradient bucket (3/4 of the bytes) is all-reduced while lane 0 is still running
         self.buckets = agent.grad_buckets() if overlap else None
@@ -95,7 +97,7 @@ class DataParallelFQL:
             return
         st = torch.cuda.current_stream().cuda_stream
         self.agent.update_begin(idxs=idxs, shard=(lo, hi), batch_size=batch_size, noise=noise, stream=st)
-        if self.world > 1:
+        if self.world > 1 or self.always_reduce:
             self.dist.all_reduce(self.grads, op=self.dist.ReduceOp.SUM, group=self.pg)
         self.agent.update_end(stream=st)
 
@@ -105,7 +107,7 @@ class DataParallelFQL:
         side = self.side_stream
         side.wait_stream(main)                       # lane 1 must not start before earlier work on the main stream
         begin(main.cuda_stream, side.cuda_stream)
-        if self.world > 1:
+        if self.world > 1 or self.always_reduce:
             with torch.cuda.stream(side):            # bucket 0 follows lane 1; overlaps the Euler chain on `main`
                 self.dist.all_reduce(self.g0, op=self.dist.ReduceOp.SUM, group=self.pg)
             self.dist.all_reduce(self.g1, op=self.dist.ReduceOp.SUM, group=self.pg)
