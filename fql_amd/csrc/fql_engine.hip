@@ -108,6 +108,7 @@ struct Op {
     LossActorArgs la;
     EulerFinishArgs ef;
     PecArgs pec;
+    int adam_c0 = 0, adam_n = -1;  // chunk range of an Adam op (-1: all chunks)
     int fin_mode = 0;
     int level = 0;
     int lane = 0;            // 0 = critical lane (Euler chain, one-step backward), 1 = side lane
@@ -199,6 +200,8 @@ struct fql_engine {
     int num_cus = 0;
     PassBuf p_os, p_os_bwd, p_bc, p_eu, p_c1[2], p_c2[2], p_ct[2];
     Program prog_fwdbwd, prog_opt, prog_loss;
+    Program prog_full;   // single-GPU update in ONE graph: per-module Adam launches start as soon as that module's gradients exist
+    int mod_chunk0[3] = {0, 0, 0}, mod_chunkn[3] = {0, 0, 0};  // chunk ranges of bc_flow, onestep, critic (leaf order)
     // data-parallel variant: the same update as three single-lane graphs (lane 0 before / after it needs lane 1, lane 1)
     // so the gradient bucket of lane 1 can be all-reduced while lane 0 is still running
     Program prog_split;
@@ -342,6 +345,16 @@ struct fql_engine {
         std::vector<int> range(n_train_leaves + 1, 0);  // chunks are emitted leaf by leaf: contiguous ranges
         for (const AdamChunk& c : ch) range[c.leaf + 1]++;
         for (int i = 0; i < n_train_leaves; ++i) range[i + 1] += range[i];
+        {   // leaves (and so chunks) are ordered module by module: actor_bc_flow, actor_onestep_flow, critic
+            const char* mods[3] = {"modules_actor_bc_flow/", "modules_actor_onestep_flow/", "modules_critic/"};
+            for (int m = 0; m < 3; ++m) {
+                int lo = 1 << 30, hi = -1;
+                for (const Leaf& lf : leaves)
+                    if (lf.trainable && lf.name.rfind(mods[m], 0) == 0) { lo = std::min(lo, lf.train_id); hi = std::max(hi, lf.train_id); }
+                mod_chunk0[m] = range[lo];
+                mod_chunkn[m] = range[hi + 1] - range[lo];
+            }
+        }
         HIP_CHECK(hipMalloc((void**)&d_leaf_range, range.size() * sizeof(int)));
         HIP_CHECK(hipMemcpy(d_leaf_range, range.data(), range.size() * sizeof(int), hipMemcpyHostToDevice));
         HIP_CHECK(hipMalloc((void**)&d_partials, (size_t)n_chunks * 4 * sizeof(float)));
@@ -1026,8 +1039,8 @@ struct fql_engine {
                     hipLaunchKernelGGL(fql_loss_actor_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.la);
                     break;
                 case OP_ADAM: {
-                    AdamArgs a{P, G, Mu, Nu, P + n_train, d_chunks, d_state, d_partials, (int)critic_size, cfg.lr, cfg.tau};
-                    hipLaunchKernelGGL(fql_adam_kernel, dim3(n_chunks), dim3(FQL_THREADS), 0, s, a);
+                    AdamArgs a{P, G, Mu, Nu, P + n_train, d_chunks, d_state, d_partials, L.op.adam_c0, (int)critic_size, cfg.lr, cfg.tau};
+                    hipLaunchKernelGGL(fql_adam_kernel, dim3(L.op.adam_n < 0 ? n_chunks : L.op.adam_n), dim3(FQL_THREADS), 0, s, a);
                     break;
                 }
                 case OP_FINALIZE:
@@ -1271,6 +1284,40 @@ struct fql_engine {
         push(pr, f);
     }
 
+    // fwd + bwd + optimizer in one graph (single-GPU calls): Adam of a module is issued on the lane that produced its
+    // gradients as soon as they exist, so 3/4 of the optimizer pass overlaps the tail of the critical lane
+    void build_full_program(Program& pr) {
+        build_step_program(pr, true);
+        DevState* st = d_state;
+        auto adam_for = [&](int m, std::initializer_list<int> net_ids, int lane) {
+            Op a{};
+            a.type = OP_ADAM;
+            a.adam_c0 = mod_chunk0[m]; a.adam_n = mod_chunkn[m];
+            a.reads = {st};
+            a.writes = {d_partials + mod_chunk0[m] * 4};
+            for (int ni : net_ids)
+                for (const Layer& L : nets[ni].layers) {
+                    a.reads.push_back(G + L.w); a.reads.push_back(G + L.b);
+                    a.writes.push_back(P + L.w);
+                    if (L.ln) { a.reads.push_back(G + L.g); a.reads.push_back(G + L.be); a.writes.push_back(P + L.g); }
+                    if (ni == NET_C0 || ni == NET_C1) a.writes.push_back(P + n_train + L.w);  // Polyak target
+                }
+            emit_lane = lane;
+            push(pr, a);
+        };
+        adam_for(2, {NET_C0, NET_C1}, 1);
+        adam_for(0, {NET_BC}, 1);
+        adam_for(1, {NET_OS}, 0);
+        Op f{};
+        f.type = OP_FINALIZE;
+        f.fin_mode = 1;
+        f.reads = {d_partials + mod_chunk0[0] * 4, d_partials + mod_chunk0[1] * 4, d_partials + mod_chunk0[2] * 4, &st->info[0],
+                   &st->info[4], &st->info[5], &st->info[7], &st->info[9]};
+        f.writes = {&st->info[10], st};
+        emit_lane = 0;
+        push(pr, f);
+    }
+
     int64_t macs_per_update() const {
         auto macs = [&](const Net& n) { int64_t m = 0; for (const Layer& L : n.layers) m += (int64_t)L.in * L.out; return m; };
         auto first = [&](const Net& n) { return (int64_t)n.layers[0].in * n.layers[0].out; };
@@ -1285,6 +1332,7 @@ struct fql_engine {
         free_program(prog_opt);
         free_program(prog_loss);
         free_program(prog_split);
+        free_program(prog_full);
         free_split();
         for (void* p : ws_allocs) hipFree(p);
         ws_allocs.clear();
@@ -1356,6 +1404,11 @@ struct fql_engine {
         build_step_program(prog_loss, false);
         schedule(prog_fwdbwd, W); schedule(prog_opt, W); schedule(prog_loss, W);
         capture(prog_fwdbwd); capture(prog_opt); capture(prog_loss);
+        if (getenv("FQL_NO_FULL") == nullptr) {
+            build_full_program(prog_full);
+            schedule(prog_full, W);
+            capture(prog_full);
+        }
         if (getenv("FQL_NO_SPLIT") == nullptr) {
             split_build = true;
             build_step_program(prog_split, true);
@@ -1363,7 +1416,8 @@ struct fql_engine {
             schedule(prog_split, W);
             split_ok = capture_split(prog_split);
         }
-        launches_per_update = (int64_t)prog_fwdbwd.launches.size() + (int64_t)prog_opt.launches.size();
+        launches_per_update = prog_full.exec ? (int64_t)prog_full.launches.size()
+                                             : (int64_t)prog_fwdbwd.launches.size() + (int64_t)prog_opt.launches.size();
         src_valid = false;
     }
 
@@ -1721,7 +1775,7 @@ static void run_program(fql_handle h, Program& pr, hipStream_t s) {
     static const bool no_graph = getenv("FQL_NO_GRAPH") != nullptr;
     static const bool split_default = getenv("FQL_SPLIT_DEFAULT") != nullptr;  // experiment: host-launched lane graphs
     if (no_graph) h->run_launches(pr, s);
-    else if (split_default && &pr == &h->prog_fwdbwd && h->split_ok && s != h->stream2) h->launch_split(s, h->stream2);
+    else if (split_default && (&pr == &h->prog_fwdbwd) && h->split_ok && s != h->stream2) h->launch_split(s, h->stream2);
     else HIP_CHECK(hipGraphLaunch(pr.exec, s));
 }
 
@@ -1747,6 +1801,14 @@ int fql_update_end(fql_handle h, float* info13, void* stream) {
 }
 int fql_update(fql_handle h, const float* obs, const float* act, const float* rew, const float* mask, const float* nobs,
                int batch_size, const fql_noise* noise, float* info13, void* stream) {
+    if (h && h->prog_full.exec && !h->began) {
+        FQL_TRY(h, {
+            hipStream_t s = pick(h, stream);
+            h->source_from_batch(obs, act, rew, mask, nobs, batch_size, noise, 1, s);
+            run_program(h, h->prog_full, s);
+            h->finish_info(info13, FQL_NUM_INFO, s);
+        });
+    }
     int rc = fql_update_begin(h, obs, act, rew, mask, nobs, batch_size, noise, stream);
     if (rc != FQL_OK) return rc;
     return fql_update_end(h, info13, stream);
@@ -1877,6 +1939,14 @@ int fql_grad_buckets(fql_handle h, size_t offsets[2], size_t lengths[2]) {
 }
 int fql_update_from_dataset(fql_handle h, const int64_t* idx, int batch_size, int64_t lo, int64_t hi, const fql_noise* noise,
                             float* info13, void* stream) {
+    if (h && h->prog_full.exec && !h->began) {
+        FQL_TRY(h, {
+            hipStream_t s = pick(h, stream);
+            h->source_from_dataset(idx, batch_size, lo, hi, noise, s);
+            run_program(h, h->prog_full, s);
+            h->finish_info(info13, FQL_NUM_INFO, s);
+        });
+    }
     int rc = fql_update_from_dataset_begin(h, idx, batch_size, lo, hi, noise, stream);
     if (rc != FQL_OK) return rc;
     return fql_update_end(h, info13, stream);

@@ -1280,6 +1280,7 @@ struct AdamArgs {
     const AdamChunk* chunks;
     DevState* st;
     float* partials;  // [n_chunks][4]: sum of squares, max, min of the (scaled) gradient chunk
+    int chunk0;       // first chunk of this launch (per-module launches of the fused single-GPU update)
     int critic_size;
     float lr, tau;
 };
@@ -1291,7 +1292,8 @@ __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i
 
 __global__ __launch_bounds__(FQL_THREADS) void fql_adam_kernel(AdamArgs A) {
     __shared__ float sh[4];
-    const AdamChunk ch = A.chunks[blockIdx.x];  // <= 4096 elements, offset and length multiples of 4
+    const int cidx = (int)blockIdx.x + A.chunk0;
+    const AdamChunk ch = A.chunks[cidx];  // <= 4096 elements, offset and length multiples of 4
     // optax bias correction with count = adam_count + 1 (the counters advance in the finalize kernel afterwards)
     const float c1 = (float)(1.0 - A.st->b1pow * 0.9), c2 = (float)(1.0 - A.st->b2pow * 0.999);
     const float gsc = A.st->grad_scale;
@@ -1331,7 +1333,7 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_adam_kernel(AdamArgs A) {
     const float tss = block_sum(ss, sh);
     const float tmx = block_max(mx, sh), tmn = -block_max(-mn, sh);
     if (threadIdx.x == 0) {
-        float* pp = A.partials + 4 * (size_t)blockIdx.x;
+        float* pp = A.partials + 4 * (size_t)cidx;
         pp[0] = tss; pp[1] = tmx; pp[2] = tmn;
     }
 }
