@@ -195,8 +195,9 @@ struct fql_engine {
     bool split_build = false;   // building the data-parallel program: lane 1 must not depend on lane 0's backward
     bool split_ok = false;
     int vp_tiles = 0;
-    unsigned* pec_cnt = nullptr;   // [teams][3 flow_steps] arrival counters + 1 error word at the end
-    size_t pec_cnt_bytes = 0;
+    int pec_teams = 0;               // teams of the persistent chain (H/32 workgroups each, one workgroup per CU)
+    unsigned* pec_epoch = nullptr;   // [teams] launch epochs of the persistent chain + 1 error word at the end
+    fql_u64 *pec_g[2] = {nullptr, nullptr}, *pec_vg = nullptr;  // granule buffers: activations [B][H] x 2, head partials [T][B][16]
     int num_cus = 0;
     PassBuf p_os, p_os_bwd, p_bc, p_eu, p_c1[2], p_c2[2], p_ct[2];
     Program prog_fwdbwd, prog_opt, prog_loss;
@@ -543,12 +544,12 @@ struct fql_engine {
         a.W0act = P + l0.w + (size_t)od * l0.out_p;
         for (int l = 0; l < 3; ++l) { a.W[l] = P + n.layers[l + 1].w; a.b[l] = P + n.layers[l + 1].b; }
         a.W4 = P + n.layers[4].w; a.b4 = P + n.layers[4].b;
-        a.Hbuf[0] = p_eu.g[1]; a.Hbuf[1] = p_eu.g[2];
-        a.Vpart = Vpart; a.tgt = tgt;
-        a.cnt = pec_cnt; a.err = pec_cnt + (size_t)(B / 16) * 3 * cfg.flow_steps;
-        a.M = B; a.ad = ad; a.ap = ap; a.flow_steps = cfg.flow_steps; a.nteams = B / 16;
+        a.G[0] = pec_g[0]; a.G[1] = pec_g[1]; a.Vg = pec_vg; a.tgt = tgt;
+        a.epoch = pec_epoch; a.err = pec_epoch + pec_teams;
+        a.M = B; a.ad = ad; a.ap = ap; a.flow_steps = cfg.flow_steps;
+        a.nteams = pec_teams; a.ntile = B / 16 / pec_teams;
         op.reads = {C0, X_eu};
-        op.writes = {tgt, p_eu.g[1], p_eu.g[2], Vpart};
+        op.writes = {tgt, pec_g[0], pec_g[1], pec_vg};
         push(pr, op);
     }
 
@@ -936,7 +937,16 @@ struct fql_engine {
                 cnt[L.lane]++;
                 int lv = -1;
                 for (int oi = 0; oi < (int)pr.ops.size(); ++oi) if (launch_of[oi] == (int)(&L - pr.launches.data())) lv = pr.ops[oi].level;
-                fprintf(stderr, "[fql] level %3d lane %d type %2d ntasks %2d grid %5d\n", lv, L.lane, (int)L.type, L.ntasks, L.grid);
+                fprintf(stderr, "[fql] level %3d lane %d type %2d ntasks %2d grid %5d :", lv, L.lane, (int)L.type, L.ntasks, L.grid);
+                for (int oi = 0; oi < (int)pr.ops.size(); ++oi) {
+                    if (launch_of[oi] != (int)(&L - pr.launches.data())) continue;
+                    const Op& o = pr.ops[oi];
+                    if (o.type == OP_GEMM || o.type == OP_GEMM64) fprintf(stderr, " g%s(%dx%dx%d%s)", o.type == OP_GEMM64 ? "64" : "16", o.gemm.M, o.gemm.N, o.gemm.K, (o.gemm.flags & GF_TRANS_B) ? "T" : "");
+                    else if (o.type == OP_WGRAD) fprintf(stderr, " w(%dx%dx%d)", o.wgrad.M, o.wgrad.Kin, o.wgrad.N);
+                    else if (o.type == OP_LNBWD) fprintf(stderr, " ln(%d)", o.ln.M);
+                    else fprintf(stderr, " t%d", (int)o.type);
+                }
+                fprintf(stderr, "\n");
             }
             fprintf(stderr, "[fql] launches per lane:");
             for (int l = 0; l < FQL_LANES; ++l) fprintf(stderr, " %d", cnt[l]);
@@ -1017,8 +1027,7 @@ struct fql_engine {
                 case OP_PEC: {
                     const PecArgs& a = L.op.pec;
                     const int T = cfg.actor_hidden[0] / 32;
-                    HIP_CHECK(hipMemsetAsync(a.cnt, 0, pec_cnt_bytes, s));
-                    const size_t lds = ((size_t)16 * (cfg.actor_hidden[0] + 4) + 1024 + 512 + 576) * sizeof(float);
+                    const size_t lds = ((size_t)16 * (cfg.actor_hidden[0] + 4) + 1024 + 576 + 512 * (size_t)a.ntile) * sizeof(float);
                     if (cfg.actor_hidden[0] == 512) hipLaunchKernelGGL((fql_euler_persistent_kernel<512>), dim3(a.nteams * T), dim3(FQL_THREADS), lds, s, a);
                     else hipLaunchKernelGGL((fql_euler_persistent_kernel<256>), dim3(a.nteams * T), dim3(FQL_THREADS), lds, s, a);
                     break;
@@ -1372,10 +1381,15 @@ struct fql_engine {
                 for (int l = 0; l < nh; ++l) same = same && nb.layers[l].out_p == H && nb.layers[l].out == H;
                 // opt-in (FQL_PEC=1): alone the chain drops from 331 to 220 us, but beside the other lanes the update time is
                 // unchanged on this box (the lanes barely overlap), so the default stays with plain launches
-                use_pec = fused_euler && same && getenv("FQL_PEC") != nullptr && (B / 16) * (H / 32) <= num_cus;
+                // teams: as many as fit one workgroup per CU; each takes B / 16 / teams row tiles
+                pec_teams = std::min(B / 16, num_cus / (H / 32));
+                while (pec_teams > 1 && (B / 16) % pec_teams) --pec_teams;
+                use_pec = fused_euler && same && getenv("FQL_PEC") != nullptr && pec_teams >= 1 && B / 16 / pec_teams <= PEC_MAX_TILES &&
+                          cfg.flow_steps <= 20;
                 if (use_pec) {
-                    pec_cnt_bytes = (((size_t)(B / 16) * 3 * cfg.flow_steps + 1) * sizeof(unsigned) + 15) & ~(size_t)15;
-                    pec_cnt = (unsigned*)dalloc(W, pec_cnt_bytes / sizeof(float));
+                    pec_epoch = (unsigned*)dalloc(W, (size_t)pec_teams + 1);
+                    for (int i = 0; i < 2; ++i) pec_g[i] = (fql_u64*)dalloc(W, (size_t)B * H * 2);
+                    pec_vg = (fql_u64*)dalloc(W, (size_t)(H / 32) * B * 16 * 2);
                 }
             }
         }
@@ -1959,7 +1973,7 @@ int fql_read_info(fql_handle h, float* info13_host) {
         HIP_CHECK(hipMemcpy(info13_host, &h->d_state->info[0], FQL_NUM_INFO * sizeof(float), hipMemcpyDeviceToHost));
         if (h->use_pec) {
             unsigned e = 0;
-            HIP_CHECK(hipMemcpy(&e, h->pec_cnt + (size_t)(h->B / 16) * 3 * h->cfg.flow_steps, sizeof e, hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(&e, h->pec_epoch + h->pec_teams, sizeof e, hipMemcpyDeviceToHost));
             if (e) throw HipError{"persistent Euler chain: a team hand-off timed out (results of this update are invalid)"};
         }
     });

@@ -1413,19 +1413,22 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_euler_finish_kernel(EulerFini
 // Persistent Euler chain (agents/fql.py:155-171): the whole 10-step x (layers 0..3 + head) chain in ONE launch.
 //
 // A kernel boundary costs ~1.6 us plus ~2.5 us of cold first loads (the per-XCD L2s are written back and
-// invalidated at every boundary), 30 times per update.  Here the 16 workgroups that own one 16-row tile of the
+// invalidated at every boundary), 30 times per update.  Here the H/32 workgroups that own one 16-row tile of the
 // batch (a "team": one 32-column slice of every hidden layer each) hand their 16 x 32 output tiles to each other
-// through L2 with the write-through / counter hand-off of the CDNA4 guide (G16 recipe, counter form):
-//   producer: every byte stored sc1 (agent-scope relaxed atomics, 8 B) -> each storing wave s_waitcnt vmcnt(0) ->
-//             __syncthreads() -> one lane: relaxed agent-scope fetch_add on the (team, phase) counter;
-//   consumer: one lane polls that counter (relaxed, agent scope, s_sleep between polls, wall-clock bounded) ->
-//             __syncthreads() -> every load of the handed-off bytes is an sc1 (agent-scope relaxed atomic) load.
-// Results do not depend on placement; teams are mapped to one XCD only for speed.  Every counter is zeroed by a
-// memset node in front of the launch; a spin that times out sets an error word and falls through, so the grid
-// always drains.  The hidden-layer weights this workgroup needs (K-half x 16 columns x 3 layers per wave) live in
-// 192 VGPRs for the whole chain, as do its slice of C0 = obs W0 + b0 and the action/t rows of W0: in steady state
-// a phase loads nothing but the 32 KB activation tile.
+// as 8-byte {tag, value} granules (CDNA4 guide, Guideline 16 form R2: the data is the flag):
+//   producer: one naturally aligned 8-byte agent-scope relaxed atomic store per value, straight from the MFMA
+//             accumulator layout -- no drain, no flag, no counter;
+//   consumer: every thread sweeps its granules of the team's 16 x H tile with 8-byte agent-scope relaxed atomic
+//             loads until every tag equals the phase tag (wall-clock bounded), then stages the values in LDS.
+// Tags never repeat: tag = (launch epoch of the team << 6) + phase index + 1, the epoch living in device memory and
+// advanced by member 0 when it has consumed the team's last phase (every member has read it by then), so neither
+// a memset node nor a per-launch argument is needed and a graph replay is safe.  A buffer is rewritten only after
+// every member has passed the phase that read it (the phase order implies it: a member can publish phase p + 2
+// only after it has gathered phase p + 1 from all members, each of which gathered phase p before publishing).
+// Results do not depend on placement; teams are mapped to one XCD only for speed.  A sweep that times out sets
+// an error word and falls through, so the grid always drains.
 // ------------------------------------------------------------------------------------------------
+typedef unsigned long long fql_u64;
 struct PecArgs {
     const float* C0;      // [M, H]  obs W0 + b0 (loop invariant)
     const float* a0;      // [M, lda0] initial actions (noise z): X_eu + obs_dim
@@ -1434,44 +1437,41 @@ struct PecArgs {
     const float* b[3];    // their biases
     const float* W4;      // head kernel [H][ap]
     const float* b4;      // head bias [ap]
-    float* Hbuf[2];       // [M, H] activation ping-pong
-    float* Vpart;         // [T][M][ap] head partials
+    fql_u64* G[2];        // [M][H] activation granules, ping-pong
+    fql_u64* Vg;          // [T][M][16] head-partial granules
     float* tgt;           // [M, ap] out: clip(a_n)
-    unsigned* cnt;        // [teams][phases] arrival counters (zeroed before the launch)
-    unsigned* err;        // set to 1 if a wait timed out
-    int M, ad, ap, lda0, flow_steps, nteams;
+    unsigned* epoch;      // [teams] launch epochs (device resident, advanced by the kernel)
+    unsigned* err;        // set to 1 if a sweep timed out
+    int M, ad, ap, lda0, flow_steps, nteams, ntile;  // nteams teams, each owning ntile 16-row tiles (team + nteams j)
 };
 
-typedef unsigned long long fql_u64;
-__device__ __forceinline__ fql_u64 ld_sc1_u64(const float* p) {
+__device__ __forceinline__ fql_u64 ld_granule(const fql_u64* p) {
     return __hip_atomic_load((const FQL_GAS fql_u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void st_sc1_u64(float* p, fql_u64 v) {
-    __hip_atomic_store((FQL_GAS fql_u64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void st_granule(fql_u64* p, unsigned tag, float v) {
+    __hip_atomic_store((FQL_GAS fql_u64*)p, ((fql_u64)tag << 32) | (fql_u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ fql_u64 pack2(float a, float b) {
-    return (fql_u64)__float_as_uint(a) | ((fql_u64)__float_as_uint(b) << 32);
-}
-// one lane waits until *c == want (relaxed agent-scope polls); bounded by wall clock (100 MHz ticks)
-__device__ __forceinline__ void pec_wait(unsigned* c, unsigned want, unsigned* err) {
-    const fql_u64 t0 = __builtin_amdgcn_s_memrealtime();
-    while (__hip_atomic_load((FQL_GAS unsigned*)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-        __builtin_amdgcn_s_sleep(2);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {  // 200 ms: something is badly wrong, drain the grid
-            __hip_atomic_store((FQL_GAS unsigned*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
+// wave-uniform: true when a spin has lasted 200 ms of wall clock (100 MHz ticks): something is badly wrong, drain the grid
+__device__ __forceinline__ bool pec_spin_fail(fql_u64& t0, unsigned* err) {
+    const fql_u64 now = __builtin_amdgcn_s_memrealtime();
+    if (t0 == 0) { t0 = now; return false; }
+    if (now - t0 > 20000000ull) {
+        __hip_atomic_store((FQL_GAS unsigned*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return true;
     }
+    return false;
 }
 
-template <int H>  // hidden width (all four hidden layers), multiple of 64; T = H / 32 members per team
+#define PEC_MAX_TILES 8
+template <int H>  // hidden width (all four hidden layers), multiple of 256; T = H / 32 members per team
 __global__ __launch_bounds__(FQL_THREADS) void fql_euler_persistent_kernel(const PecArgs P) {
     constexpr int T = H / 32, S = H + 4, G2 = H / 32;  // G2 = k-groups (of 16) per K-half
     constexpr int CT = H / 64;                          // layer-0 column tiles per wave
+    constexpr int KPR = H / FQL_THREADS;                // granule sweeps per row of the activation tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* red = lds + 16 * S;   // [2 column tiles][64] float4: K-split partials
-    float* ea = red + 1024;      // [16][32] current actions a_s (persistent across steps)
-    float* hs = ea + 512;        // [16][36] staging: output tile / last-hidden tile
+    float* hs = red + 1024;      // [16][36] staging: last-hidden tile for the head partial
+    float* eas = hs + 576;       // [ntile][16][32] current actions a_s of every row tile (persistent across steps)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 15, q = lane >> 4;
     const int nt = wave & 1, kp = wave >> 1;
@@ -1483,14 +1483,18 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_euler_persistent_kernel(const
     } else {
         team = blockIdx.x / T; mem = blockIdx.x % T;
     }
-    const int row0 = team * 16, n0 = mem * 32 + nt * 16;
+    // a team owns the 16-row tiles team, team + nteams, ...: every phase runs over all of them in turn, so the
+    // granules a tile needs were published a whole round earlier and their flight time hides behind the other tiles
+    const int ntile = P.ntile;
+    const int n0 = mem * 32 + nt * 16;
     const int M = P.M, ad = P.ad, ap = P.ap;
-    unsigned* cnt = P.cnt + (size_t)team * (3 * P.flow_steps);
+    const unsigned ep = __hip_atomic_load((FQL_GAS unsigned*)(P.epoch + team), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned tag0 = ep << 6;  // phase tags of this launch: tag0 + 1 .. tag0 + 3 flow_steps (< 64)
 
-    // ---- operands.  The hidden-layer B fragments (K-half x 16 columns = 4 G2 VGPRs) are re-fetched every phase, but
-    // BEFORE the wait for the team (they do not depend on the hand-off) and from an L2 that is never invalidated
-    // inside this launch; keeping all three layers resident instead (192 VGPRs) would push the kernel to 450
-    // VGPRs and evict every other lane's waves from the CUs for the length of the chain.
+    // ---- operands.  The hidden-layer B fragments (K-half x 16 columns = 4 G2 VGPRs) are fetched once per phase (for
+    // all row tiles), BEFORE the sweep for the team's tile (they do not depend on it) and from an L2 that is never
+    // invalidated inside this launch; keeping all three layers resident instead (192 VGPRs) would push the kernel
+    // to 450 VGPRs and evict every other lane's waves from the CUs for the length of the chain.
     float wb[4 * G2];  // element (k = 16 (kp G2 + g) + 4 q + s, n0 + c) of the current layer
     auto load_w = [&](const float* Wl) {
         // the per-lane base is made opaque so the 4 G2 load addresses are formed here, next to the loads: hoisted
@@ -1510,13 +1514,12 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_euler_persistent_kernel(const
     for (int g = 0; g < 2; ++g)
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) bw4[4 * g + s4] = ldg(P.W4 + (size_t)(mem * 32 + 16 * g + 4 * q + s4) * ap + c);
-    // a_0 (+ zero fill of the [16][32] block); column ad carries t_s
-    for (int e = tid; e < 16 * 32; e += FQL_THREADS) {
-        const int r = e >> 5, j = e & 31;
-        ea[e] = (j < ad) ? ldg(P.a0 + (size_t)(row0 + r) * P.lda0 + j) : 0.f;
+    // a_0 (+ zero fill of the [16][32] blocks); column ad carries t_s
+    for (int e = tid; e < ntile * 512; e += FQL_THREADS) {
+        const int j = e >> 9, r = (e >> 5) & 15, col = e & 31;
+        eas[e] = (col < ad) ? ldg(P.a0 + (size_t)((team + P.nteams * j) * 16 + r) * P.lda0 + col) : 0.f;
     }
     const float inv_steps = 1.0f / (float)P.flow_steps;
-    int phase = 0;  // global phase index of this team: 3 per Euler step
 
     auto gemm_phase = [&](const float (&wl)[4 * G2]) -> f32x4 {  // A tile in LDS -> 16 x 16 accumulator (kp 0 holds the sum)
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
@@ -1537,119 +1540,126 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_euler_persistent_kernel(const
         if (kp == 0) acc += *reinterpret_cast<const f32x4*>(&red[(nt * 64 + lane) * 4]);
         return acc;
     };
-    auto signal = [&]() {  // every storing wave drained, then one lane announces this workgroup's tile
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add((FQL_GAS unsigned*)(cnt + phase), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ++phase;
-    };
-    auto wait_prev = [&]() {  // all T members have published phase - 1
-        if (tid == 0) pec_wait(cnt + phase - 1, (unsigned)T, P.err);
-        __syncthreads();
-    };
-    auto publish_tile = [&](const f32x4& acc, float bl, float* dst) {  // GELU tile -> hs -> 8-byte sc1 stores of whole rows
+    // GELU tile -> granules, straight from the accumulator layout (col = c, rows 4 q + i): 16 lanes = 128 contiguous bytes
+    auto publish_tile = [&](const f32x4& acc, float bl, fql_u64* dst, int row0, unsigned tag) {
         if (kp == 0) {
+            fql_u64* d = dst + (size_t)(row0 + 4 * q) * H + n0 + c;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) hs[(4 * q + i) * 36 + 16 * nt + c] = gelu_f(acc[i] + bl);
-        }
-        __syncthreads();
-        {   // 16 rows x 32 floats = 256 pairs: one 8-byte store per thread
-            const int r = tid >> 4, j2 = (tid & 15) * 2;
-            st_sc1_u64(dst + (size_t)(row0 + r) * H + mem * 32 + j2, pack2(hs[r * 36 + j2], hs[r * 36 + j2 + 1]));
+            for (int i = 0; i < 4; ++i) st_granule(d + (size_t)i * H, tag, gelu_f(acc[i] + bl));
         }
     };
-    auto load_tile = [&](const float* src) {  // 16 x H floats, sc1 loads, 8 B each
-        constexpr int NP = 16 * H / 2 / FQL_THREADS;  // pairs per thread
-        fql_u64 v[NP];
-        // thread t covers pairs f = t + 256 i: row = i (256 pairs = one row of 512 floats when H = 512) -- keep the
-        // generic form but from an opaque base so the NP addresses are not hoisted out of the step loop
-        const float* sb = src + (size_t)row0 * H;
+    // a 16 x H tile: thread t sweeps granules t + 256 k (row k / KPR) until all carry `tag`, then stages them in LDS
+    auto gather_tile = [&](const fql_u64* src, int row0, unsigned tag) {
+        const fql_u64* sb = src + (size_t)row0 * H + tid;
         asm volatile("" : "+v"(sb));
+        constexpr int NG = 16 * KPR;
+        fql_u64 v[NG];
+        fql_u64 t0 = 0;
+        for (;;) {
+            bool ok = true;
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int f = tid + i * FQL_THREADS;
-            const int r = f / (H / 2), j2 = (f - r * (H / 2)) * 2;
-            v[i] = ld_sc1_u64(sb + (size_t)r * H + j2);
+            for (int i = 0; i < NG; ++i) {
+                v[i] = ld_granule(sb + (size_t)i * FQL_THREADS);
+                ok &= (unsigned)(v[i] >> 32) == tag;
+            }
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (pec_spin_fail(t0, P.err)) break;
         }
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int f = tid + i * FQL_THREADS;
-            const int r = f / (H / 2), j2 = (f - r * (H / 2)) * 2;
-            lds[r * S + j2] = __uint_as_float((unsigned)v[i]);
-            lds[r * S + j2 + 1] = __uint_as_float((unsigned)(v[i] >> 32));
+        for (int i = 0; i < NG; ++i) lds[(i / KPR) * S + tid + FQL_THREADS * (i % KPR)] = __uint_as_float((unsigned)v[i]);
+    };
+    // fold the T head partials of the previous phase C in fixed order: thread (r, j) owns action element (row0 + r, j)
+    auto gather_head = [&](int row0, unsigned tag) -> float {
+        const int r = tid >> 4, j = tid & 15;
+        const bool act = j < ad;
+        const fql_u64* vb = P.Vg + ((size_t)row0 + r) * 16 + (act ? j : 0);
+        fql_u64 v[T];
+        fql_u64 t0 = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int tp = 0; tp < T; ++tp) {
+                v[tp] = ld_granule(vb + (size_t)tp * M * 16);
+                ok &= (unsigned)(v[tp] >> 32) == tag;
+            }
+            if (__all(ok || !act)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (pec_spin_fail(t0, P.err)) break;
         }
+        float sum = 0.f;
+#pragma unroll
+        for (int tp = 0; tp < T; ++tp) sum += __uint_as_float((unsigned)v[tp]);
+        return sum;
     };
 
 #pragma clang loop unroll(disable)
     for (int s = 0; s < P.flow_steps; ++s) {
+        const unsigned tagA = tag0 + 3 * s + 1, tagB = tagA + 1, tagC = tagA + 2;
         // ---------------- phase A: fold head partials -> a_s ; layer 0 (rank update of C0) ; layer 1
         load_w(P.W[0]);
-        f32x4 c0f[CT];      // C0 in C layout for this wave's layer-0 column tiles (wave + 4 t)
-        float wf[CT][4];    // W0 action/t rows for the same tiles
+        float wf[CT][4];    // W0 action/t rows for this wave's layer-0 column tiles (wave + 4 t)
         {
-            const float* cb = P.C0 + (size_t)(row0 + 4 * q) * H + 16 * wave + c;
             const float* wb0 = P.W0act + (size_t)(4 * q) * H + 16 * wave + c;
-            asm volatile("" : "+v"(cb), "+v"(wb0));
+            asm volatile("" : "+v"(wb0));
 #pragma unroll
-            for (int t = 0; t < CT; ++t) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) c0f[t][i] = ldg(cb + (size_t)i * H + 64 * t);
+            for (int t = 0; t < CT; ++t)
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) wf[t][s4] = ldg(wb0 + (size_t)s4 * H + 64 * t);
-            }
         }
-        if (s > 0) {
-            wait_prev();
-            if (tid < 16 * 16) {
-                const int r = tid >> 4, j = tid & 15;
-                if (j < ad) {
-                    float sum = 0.f;
-                    float pv[T];
+#pragma clang loop unroll(disable)
+        for (int j = 0; j < ntile; ++j) {
+            const int row0 = (team + P.nteams * j) * 16;
+            float* ea = eas + 512 * j;
+            f32x4 c0f[CT];      // C0 in C layout for the same column tiles
+            {
+                const float* cb = P.C0 + (size_t)(row0 + 4 * q) * H + 16 * wave + c;
+                asm volatile("" : "+v"(cb));
 #pragma unroll
-                    for (int tp = 0; tp < T; ++tp) pv[tp] = __uint_as_float((unsigned)__hip_atomic_load(
-                        (const FQL_GAS unsigned*)(P.Vpart + ((size_t)tp * M + row0 + r) * ap + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                for (int t = 0; t < CT; ++t)
 #pragma unroll
-                    for (int tp = 0; tp < T; ++tp) sum += pv[tp];
-                    ea[r * 32 + j] += (sum + ldg(P.b4 + j)) * inv_steps;
+                    for (int i = 0; i < 4; ++i) c0f[t][i] = ldg(cb + (size_t)i * H + 64 * t);
+            }
+            if (s > 0) {
+                const float sum = gather_head(row0, tagA - 1);  // phase C of step s - 1
+                const int r = tid >> 4, jj = tid & 15;
+                if (jj < ad) ea[r * 32 + jj] += (sum + ldg(P.b4 + jj)) * inv_steps;
+            }
+            if (tid < 16) ea[tid * 32 + ad] = (float)s * inv_steps;  // t_s
+            __syncthreads();
+            {
+                const f32x4 af = *reinterpret_cast<const f32x4*>(&ea[c * 32 + 4 * q]);
+#pragma unroll
+                for (int t = 0; t < CT; ++t) {
+                    f32x4 h = c0f[t];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) h = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s4], wf[t][s4], h, 0, 0, 0);
+                    const int ct = wave + 4 * t;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) lds[(4 * q + i) * S + 16 * ct + c] = gelu_f(h[i]);
                 }
             }
-        }
-        if (tid < 16) ea[tid * 32 + ad] = (float)s * inv_steps;  // t_s
-        __syncthreads();
-        {
-            const f32x4 af = *reinterpret_cast<const f32x4*>(&ea[c * 32 + 4 * q]);
-#pragma unroll
-            for (int t = 0; t < CT; ++t) {
-                f32x4 h = c0f[t];
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) h = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s4], wf[t][s4], h, 0, 0, 0);
-                const int ct = wave + 4 * t;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) lds[(4 * q + i) * S + 16 * ct + c] = gelu_f(h[i]);
-            }
-        }
-        __syncthreads();
-        {
+            __syncthreads();
             const f32x4 acc = gemm_phase(wb);
-            publish_tile(acc, bias[0], P.Hbuf[0]);
-            signal();
+            publish_tile(acc, bias[0], P.G[0], row0, tagA);
         }
         // ---------------- phase B: layer 2
         load_w(P.W[1]);
-        wait_prev();
-        load_tile(P.Hbuf[0]);
-        __syncthreads();
-        {
+#pragma clang loop unroll(disable)
+        for (int j = 0; j < ntile; ++j) {
+            const int row0 = (team + P.nteams * j) * 16;
+            gather_tile(P.G[0], row0, tagA);
+            __syncthreads();
             const f32x4 acc = gemm_phase(wb);
-            publish_tile(acc, bias[1], P.Hbuf[1]);
-            signal();
+            publish_tile(acc, bias[1], P.G[1], row0, tagB);
         }
         // ---------------- phase C: layer 3 + head partial
         load_w(P.W[2]);
-        wait_prev();
-        load_tile(P.Hbuf[1]);
-        __syncthreads();
-        {
+#pragma clang loop unroll(disable)
+        for (int j = 0; j < ntile; ++j) {
+            const int row0 = (team + P.nteams * j) * 16;
+            gather_tile(P.G[1], row0, tagB);
+            __syncthreads();
             const f32x4 acc = gemm_phase(wb);
             if (kp == 0) {
 #pragma unroll
@@ -1664,32 +1674,23 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_euler_persistent_kernel(const
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4) pa = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s4], bw4[4 * g + s4], pa, 0, 0, 0);
                 }
-                if (c < ap) {
+                if (c < ad) {
+                    fql_u64* d = P.Vg + ((size_t)mem * M + row0 + 4 * q) * 16 + c;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        __hip_atomic_store((FQL_GAS unsigned*)(P.Vpart + ((size_t)mem * M + row0 + 4 * q + i) * ap + c),
-                                           __float_as_uint(pa[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int i = 0; i < 4; ++i) st_granule(d + (size_t)i * 16, tagC, pa[i]);
                 }
             }
-            signal();
         }
     }
-    // ---------------- final: member 0 folds the last partials and writes clip(a_n)
+    // ---------------- final: member 0 folds the last partials, writes clip(a_n) and advances the team's epoch
     if (mem == 0) {
-        wait_prev();
-        if (tid < 16 * 16) {
-            const int r = tid >> 4, j = tid & 15;
-            if (j < ad) {
-                float sum = 0.f;
-                float pv[T];
-#pragma unroll
-                for (int tp = 0; tp < T; ++tp) pv[tp] = __uint_as_float((unsigned)__hip_atomic_load(
-                    (const FQL_GAS unsigned*)(P.Vpart + ((size_t)tp * M + row0 + r) * ap + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-#pragma unroll
-                for (int tp = 0; tp < T; ++tp) sum += pv[tp];
-                stg(P.tgt + (size_t)(row0 + r) * ap + j, clip1(ea[r * 32 + j] + (sum + ldg(P.b4 + j)) * inv_steps));
-            }
+        for (int j = 0; j < ntile; ++j) {
+            const int row0 = (team + P.nteams * j) * 16;
+            const float sum = gather_head(row0, tag0 + 3 * P.flow_steps);
+            const int r = tid >> 4, jj = tid & 15;
+            if (jj < ad) stg(P.tgt + (size_t)(row0 + r) * ap + jj, clip1(eas[512 * j + r * 32 + jj] + (sum + ldg(P.b4 + jj)) * inv_steps));
         }
+        if (tid == 0) __hip_atomic_store((FQL_GAS unsigned*)(P.epoch + team), ep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -48,6 +48,8 @@ from typing import Dict, Tuple
 
 import numpy as np
 
+from oracle import encoder_oracle as ENC
+
 SQRT_2_OVER_PI = math.sqrt(2.0 / math.pi)
 GELU_C = 0.044715
 LN_EPS = 1e-6
@@ -185,6 +187,11 @@ def init_params(seed: int, obs_dim: int, act_dim: int, config: dict, dtype=np.fl
     rng = np.random.default_rng(seed)
     vh = tuple(config['value_hidden_dims'])
     ah = tuple(config['actor_hidden_dims'])
+    enc_name = config.get('encoder')
+    ob_shape = None
+    if enc_name is not None:   # agents/fql.py:196-202: obs_dim is the image shape (H, W, C); the MLPs see the encoding
+        ob_shape = tuple(obs_dim)
+        obs_dim = ENC.encoder_out_dim(enc_name)
 
     def actor(in_dim, ln):
         dims = (in_dim,) + ah + (act_dim,)
@@ -217,6 +224,12 @@ def init_params(seed: int, obs_dim: int, act_dim: int, config: dict, dtype=np.fl
         'modules_actor_bc_flow': actor(obs_dim + act_dim + 1, config['actor_layer_norm']),
         'modules_actor_onestep_flow': actor(obs_dim + act_dim, config['actor_layer_norm']),
     }
+    if enc_name is not None:
+        # one encoder per module (agents/fql.py:199-202).  `actor_bc_flow_encoder` (agents/fql.py:230-232) is the SAME
+        # module instance as actor_bc_flow's encoder; it is restated here as sharing that parameter set (author intent per
+        # the comment there; whether flax stores it once or twice could not be checked: SURVEY.md 8f N1).
+        for m in ('modules_critic', 'modules_actor_bc_flow', 'modules_actor_onestep_flow'):
+            params[m]['encoder'] = ENC.init_encoder_params(rng, ob_shape, enc_name, dtype)
     params['modules_target_critic'] = copy.deepcopy(params['modules_critic'])
     return params
 
@@ -250,13 +263,23 @@ class OracleFQL:
     def __init__(self, params: dict, config: dict, obs_dim: int, act_dim: int, dtype=np.float32):
         self.dtype = np.dtype(dtype)
         self.config = dict(config)
-        self.obs_dim, self.act_dim = obs_dim, act_dim
+        self.enc_name = self.config.get('encoder')
+        self.ob_shape = tuple(obs_dim) if self.enc_name is not None else None
+        self.obs_dim = ENC.encoder_out_dim(self.enc_name) if self.enc_name is not None else obs_dim
+        self.act_dim = act_dim
         self.params = tree_map(lambda a: np.array(a, dtype=self.dtype), params)
         # optax.adam state: count=0, mu=0, nu=0 (agents/fql.py:237, utils/flax_utils.py:74-76)
         self.mu = tree_map(np.zeros_like, self.params)
         self.nu = tree_map(np.zeros_like, self.params)
         self.count = 0
         self.step = 1  # utils/flax_utils.py:81
+        # test hook: when set, every use the reference makes with params=None (stored params, constants under jax.grad:
+        # utils/flax_utils.py:90-118) reads this tree instead of self.params, so finite differences of total_loss w.r.t.
+        # self.params see exactly the dependence jax.grad differentiates
+        self.frozen = None
+
+    def _P(self, stored=False):
+        return self.frozen if (stored and self.frozen is not None) else self.params
 
     @classmethod
     def create(cls, seed, obs_dim, act_dim, config, dtype=np.float32):
@@ -266,14 +289,21 @@ class OracleFQL:
     def _c(self, x):
         return np.asarray(x, dtype=self.dtype)
 
-    def _actor(self, name, obs, act, t=None, keep=False):
+    def _enc(self, name, obs, keep=False, stored=False):
+        """Module `name`'s encoder applied to raw observations (identity for state-based agents)."""
+        if self.enc_name is None:
+            return (self._c(obs), None) if keep else self._c(obs)
+        return ENC.impala_forward(self._P(stored)[name]['encoder'], obs, keep=keep, dtype=self.dtype.type)
+
+    def _actor(self, name, obs, act, t=None, keep=False, stored=False):
+        """`obs` is already encoded (utils/networks.py:221-222 with the encoder applied by the caller)."""
         xs = [obs, act] if t is None else [obs, act, t]
         x = np.concatenate(xs, axis=-1)
-        return mlp_forward(self.params[name]['mlp'], x, keep=keep)
+        return mlp_forward(self._P(stored)[name]['mlp'], x, keep=keep)
 
-    def _critic(self, name, obs, act, keep=False):
+    def _critic(self, name, obs, act, keep=False, stored=False):
         x = np.concatenate([obs, act], axis=-1)
-        net = self.params[name]['value_net']
+        net = self._P(stored)[name]['value_net']
         outs, caches = [], []
         for e in range(2):
             r = mlp_forward(net, x, member=e, keep=keep)
@@ -287,25 +317,27 @@ class OracleFQL:
     # -- public API -----------------------------------------------------------------
     def sample_actions(self, observations, noises):
         """agents/fql.py:135-153 with the normal draw passed in."""
-        a = self._actor('modules_actor_onestep_flow', self._c(observations), self._c(noises))
+        a = self._actor('modules_actor_onestep_flow', self._enc('modules_actor_onestep_flow', observations, stored=True),
+                        self._c(noises), stored=True)
         return np.clip(a, -1, 1)
 
     def compute_flow_actions(self, observations, noises):
         """agents/fql.py:155-171."""
-        obs = self._c(observations)
+        obs = self._enc('modules_actor_bc_flow', observations, stored=True)  # encoded once (agents/fql.py:162-163, is_encoded=True :168)
         a = self._c(noises)
         n = int(self.config['flow_steps'])
         for i in range(n):
             t = np.full(obs.shape[:-1] + (1,), i / n, dtype=self.dtype)
-            v = self._actor('modules_actor_bc_flow', obs, a, t)
+            v = self._actor('modules_actor_bc_flow', obs, a, t, stored=True)
             a = a + v / self.dtype.type(n)
         return np.clip(a, -1, 1)
 
     def _losses(self, batch, noise, want_grads: bool):
         cfg = self.config
         dt = self.dtype.type
-        obs = self._c(batch['observations']); act = self._c(batch['actions'])
-        nobs = self._c(batch['next_observations'])
+        vis = self.enc_name is not None
+        raw_obs, raw_nobs = batch['observations'], batch['next_observations']
+        act = self._c(batch['actions'])
         rew = self._c(batch['rewards']).reshape(-1); mask = self._c(batch['masks']).reshape(-1)
         eps1, x0, z, eps2 = (self._c(noise[k]) for k in ('eps1', 'x0', 'z', 'eps2'))
         t = self._c(noise['t']).reshape(-1, 1)
@@ -313,11 +345,13 @@ class OracleFQL:
         info = {}
 
         # ---- critic loss (agents/fql.py:22-44)
-        next_actions = np.clip(self.sample_actions(nobs, eps1), -1, 1)
-        next_qs = self._critic('modules_target_critic', nobs, next_actions)
+        next_actions = np.clip(self.sample_actions(raw_nobs, eps1), -1, 1)
+        next_qs = self._critic('modules_target_critic', self._enc('modules_target_critic', raw_nobs, stored=True), next_actions,
+                               stored=True)
         next_q = next_qs.min(axis=0) if cfg['q_agg'] == 'min' else next_qs.mean(axis=0)
         target_q = rew + dt(cfg['discount']) * mask * next_q
-        q, c_caches = self._critic('modules_critic', obs, act, keep=True)
+        obs_c, enc_c_cache = self._enc('modules_critic', raw_obs, keep=True)
+        q, c_caches = self._critic('modules_critic', obs_c, act, keep=True)
         critic_loss = np.square(q - target_q).mean()
         info['critic/critic_loss'] = critic_loss
         info['critic/q_mean'] = q.mean(); info['critic/q_max'] = q.max(); info['critic/q_min'] = q.min()
@@ -325,15 +359,19 @@ class OracleFQL:
         # ---- actor loss (agents/fql.py:46-92)
         x_t = (1 - t) * x0 + t * act
         vel = act - x0
-        pred, bc_cache = self._actor('modules_actor_bc_flow', obs, x_t, t, keep=True)
+        obs_bc, enc_bc_cache = self._enc('modules_actor_bc_flow', raw_obs, keep=True)
+        pred, bc_cache = self._actor('modules_actor_bc_flow', obs_bc, x_t, t, keep=True)
         bc_flow_loss = np.mean((pred - vel) ** 2)
 
-        target_flow_actions = self.compute_flow_actions(obs, z)
-        a_raw, os_cache = self._actor('modules_actor_onestep_flow', obs, z, keep=True)
+        target_flow_actions = self.compute_flow_actions(raw_obs, z)
+        obs_os, enc_os_cache = self._enc('modules_actor_onestep_flow', raw_obs, keep=True)
+        a_raw, os_cache = self._actor('modules_actor_onestep_flow', obs_os, z, keep=True)
         distill_loss = np.mean((a_raw - target_flow_actions) ** 2)
 
         a_clip = np.clip(a_raw, -1, 1)
-        qs, q_caches = self._critic('modules_critic', obs, a_clip, keep=True)
+        # agents/fql.py:70: critic called with params=None -> stored params (same encoder, same obs: same encoding as obs_c)
+        obs_cs = obs_c if self.frozen is None else self._enc('modules_critic', raw_obs, stored=True)
+        qs, q_caches = self._critic('modules_critic', obs_cs, a_clip, keep=True, stored=True)
         qm = qs.mean(axis=0)
         q_loss = -qm.mean()
         lam = dt(1.0)
@@ -342,7 +380,7 @@ class OracleFQL:
             q_loss = lam * q_loss
         actor_loss = bc_flow_loss + dt(cfg['alpha']) * distill_loss + q_loss
 
-        actions = self.sample_actions(obs, eps2)
+        actions = self.sample_actions(raw_obs, eps2)
         mse = np.mean((actions - act) ** 2)
         info.update({'actor/actor_loss': actor_loss, 'actor/bc_flow_loss': bc_flow_loss,
                      'actor/distill_loss': distill_loss, 'actor/q_loss': q_loss,
@@ -358,28 +396,38 @@ class OracleFQL:
         cnet = self.params['modules_critic']['value_net']
         gc = grads['modules_critic']['value_net']
         dq = (2.0 / (2 * B)) * (q - target_q)  # [2,B]
+        d_enc = 0
         for e in range(2):
-            _, g = mlp_backward(cnet, c_caches[e], dq[e][:, None].astype(self.dtype), member=e)
+            dx, g = mlp_backward(cnet, c_caches[e], dq[e][:, None].astype(self.dtype), member=e)
+            d_enc = d_enc + dx[:, :self.obs_dim]
             for ln, sub in g.items():
                 for k, v in sub.items():
                     gc[ln][k][e] = v
+        if vis:  # the critic's encoder sees only the critic loss (the actor loss calls the critic with constant params)
+            grads['modules_critic']['encoder'] = ENC.impala_backward(self.params['modules_critic']['encoder'], enc_c_cache, d_enc)
 
         # bc_flow params <- bc_flow_loss
         dpred = (2.0 / (B * A)) * (pred - vel)
-        _, g = mlp_backward(self.params['modules_actor_bc_flow']['mlp'], bc_cache, dpred.astype(self.dtype))
+        dx, g = mlp_backward(self.params['modules_actor_bc_flow']['mlp'], bc_cache, dpred.astype(self.dtype))
         grads['modules_actor_bc_flow']['mlp'] = g
+        if vis:  # the distillation target is computed outside the gradient (agents/fql.py:64: no params passed)
+            grads['modules_actor_bc_flow']['encoder'] = ENC.impala_backward(
+                self.params['modules_actor_bc_flow']['encoder'], enc_bc_cache, dx[:, :self.obs_dim])
 
         # onestep params <- alpha*distill + q_loss (critic params constant: params=None, flax_utils.py:90-118)
         da = dt(cfg['alpha']) * (2.0 / (B * A)) * (a_raw - target_flow_actions)
         dact = np.zeros_like(a_raw)
         for e in range(2):
             dqe = np.full((B, 1), -lam / (2 * B), dtype=self.dtype)
-            dx, _ = mlp_backward(cnet, q_caches[e], dqe, member=e, want_param_grads=False)
+            dx, _ = mlp_backward(self._P(True)['modules_critic']['value_net'], q_caches[e], dqe, member=e, want_param_grads=False)
             dact += dx[:, self.obs_dim:self.obs_dim + A]
         inside = (a_raw > -1) & (a_raw < 1)
         da = da + dact * inside
-        _, g = mlp_backward(self.params['modules_actor_onestep_flow']['mlp'], os_cache, da.astype(self.dtype))
+        dx, g = mlp_backward(self.params['modules_actor_onestep_flow']['mlp'], os_cache, da.astype(self.dtype))
         grads['modules_actor_onestep_flow']['mlp'] = g
+        if vis:
+            grads['modules_actor_onestep_flow']['encoder'] = ENC.impala_backward(
+                self.params['modules_actor_onestep_flow']['encoder'], enc_os_cache, dx[:, :self.obs_dim])
         return loss, info, grads
 
     def total_loss(self, batch, noise):

@@ -37,10 +37,12 @@ def test_checkpoint_roundtrip_resumes_bit_identically(tmp_path):
     assert b.get_opt_state()['count'] == 4
 
 
-def test_persistent_euler_chain_matches_oracle():
-    """FQL_PEC=1: the whole Euler chain in one persistent launch (team hand-offs through L2)."""
+@pytest.mark.parametrize('B', [256, 512])
+def test_persistent_euler_chain_matches_oracle(B):
+    """FQL_PEC=1: the whole Euler chain in one persistent launch (team hand-offs as {tag, value} granules);
+    B=512 gives every team two row tiles, which it runs through each phase in turn."""
     import fql_amd
-    od, ad, B = 29, 8, 256
+    od, ad = 29, 8
     os.environ['FQL_PEC'] = '1'
     try:
         cfg, ds, batch, noise = make_problem(od, ad, B, (512, 512, 512, 512), seed=17)
