@@ -24,7 +24,8 @@ class FqlConfig(C.Structure):
         ('layer_norm', C.c_int32), ('actor_layer_norm', C.c_int32),
         ('lr', C.c_float), ('discount', C.c_float), ('tau', C.c_float), ('alpha', C.c_float),
         ('q_agg', C.c_int32), ('flow_steps', C.c_int32), ('normalize_q_loss', C.c_int32),
-        ('batch_size', C.c_int32), ('precision', C.c_int32), ('reserved', C.c_int32 * 7),
+        ('batch_size', C.c_int32), ('precision', C.c_int32), ('encoder', C.c_int32), ('img_h', C.c_int32),
+        ('img_w', C.c_int32), ('img_c', C.c_int32), ('reserved', C.c_int32 * 3),
     ]
 
 

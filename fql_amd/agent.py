@@ -53,7 +53,7 @@ def _seed_to_u64(seed) -> int:
 class _Arg:
     """fp32 contiguous view of a user array + the pointer handed to the C ABI (device or host)."""
 
-    def __init__(self, x, shape=None):
+    def __init__(self, x, shape=None, u8=False):
         self.keep = None
         if x is None:
             self.ptr = None
@@ -61,15 +61,16 @@ class _Arg:
         if hasattr(x, 'data_ptr'):  # torch tensor (cuda or cpu)
             torch = _torch()
             t = x.detach()
-            if t.dtype != torch.float32:
-                t = t.float()
+            want = torch.uint8 if u8 else torch.float32
+            if t.dtype != want:
+                t = t.to(want)
             t = t.contiguous()
             if shape is not None and int(np.prod(shape)) != t.numel():
                 raise ValueError(f'expected {int(np.prod(shape))} elements, got shape {tuple(t.shape)}')
             self.keep = t
             self.ptr = t.data_ptr()
         else:
-            a = np.ascontiguousarray(np.asarray(x), dtype=np.float32)
+            a = np.ascontiguousarray(np.asarray(x), dtype=np.uint8 if u8 else np.float32)
             if shape is not None and int(np.prod(shape)) != a.size:
                 raise ValueError(f'expected {int(np.prod(shape))} elements, got shape {a.shape}')
             self.keep = a
@@ -97,16 +98,24 @@ class FQLAgent:
         lib = _cabi.load()
         cfg = get_config()
         cfg.update(dict(config))
-        if cfg.get('encoder') is not None:
-            raise NotImplementedError('visual encoders (impala_small) are not on the built path yet (SURVEY.md 8f N1)')
         ex_observations = np.asarray(ex_observations) if not hasattr(ex_observations, 'shape') else ex_observations
-        ob_dims = tuple(ex_observations.shape[1:])
-        if len(ob_dims) != 1:
-            raise ValueError(f'state-based observations expected, got ob_dims={ob_dims}')
+        ob_dims = tuple(int(d) for d in ex_observations.shape[1:])
         action_dim = int(ex_actions.shape[-1])
         c = _cabi.FqlConfig()
         lib.fql_default_config(C.byref(c))
-        c.obs_dim, c.act_dim = int(ob_dims[0]), action_dim
+        if cfg.get('encoder') is not None:
+            # agents/fql.py:196-202: one encoder per module in front of the MLPs; observations are uint8 images [H, W, C]
+            if cfg['encoder'] != 'impala_small':
+                raise NotImplementedError(f"encoder {cfg['encoder']!r}: only 'impala_small' (utils/encoders.py:106) is built")
+            if len(ob_dims) != 3:
+                raise ValueError(f'image observations [H, W, C] expected with an encoder, got ob_dims={ob_dims}')
+            c.encoder, c.img_h, c.img_w, c.img_c = 1, ob_dims[0], ob_dims[1], ob_dims[2]
+            c.obs_dim = 1
+        else:
+            if len(ob_dims) != 1:
+                raise ValueError(f'state-based observations expected, got ob_dims={ob_dims}')
+            c.obs_dim = int(ob_dims[0])
+        c.act_dim = action_dim
         ah, vh = tuple(cfg['actor_hidden_dims']), tuple(cfg['value_hidden_dims'])
         if len(ah) > _cabi.FQL_MAX_HIDDEN or len(vh) > _cabi.FQL_MAX_HIDDEN:
             raise ValueError('too many hidden layers')
@@ -157,12 +166,13 @@ class FQLAgent:
 
     def _batch_args(self, batch):
         B = int(np.shape(batch['actions'])[0]) if not hasattr(batch['actions'], 'shape') else int(batch['actions'].shape[0])
-        od, ad = self.config['ob_dims'][0], self.config['action_dim']
-        shapes = {'observations': (B, od), 'actions': (B, ad), 'rewards': (B,), 'masks': (B,), 'next_observations': (B, od)}
+        obd, ad = tuple(self.config['ob_dims']), self.config['action_dim']
+        shapes = {'observations': (B,) + obd, 'actions': (B, ad), 'rewards': (B,), 'masks': (B,), 'next_observations': (B,) + obd}
         for k in BATCH_KEYS:
             if k not in batch:
                 raise KeyError(f'batch is missing {k!r}')
-        return B, [_Arg(batch[k], shapes[k]) for k in BATCH_KEYS]
+        vis = len(obd) == 3   # image observations travel as uint8 (utils/encoders.py:84 divides by 255 on the device)
+        return B, [_Arg(batch[k], shapes[k], u8=vis and k.endswith('observations')) for k in BATCH_KEYS]
 
     def _noise_args(self, noise, B):
         if noise is None:

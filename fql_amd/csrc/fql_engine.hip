@@ -11,6 +11,7 @@
 // utils/flax_utils.py:90-159, utils/datasets.py:64-100,435-495 (zhouzypaul/fql).
 #include "../../include/fql_amd.h"
 #include "fql_kernels.h"
+#include "fql_conv.h"
 
 #include <algorithm>
 #include <cmath>
@@ -75,6 +76,25 @@ struct Net {
 };
 enum { NET_C0 = 0, NET_C1, NET_BC, NET_OS, NET_T0, NET_T1, NUM_NETS };
 
+// IMPALA encoder in the arena (utils/encoders.py:61-100): per stack 1 + 2 num_blocks convolutions, then Dense + GELU.
+// A convolution leaf is stored exactly as flax lays it out, [3][3][cin][cout] = [tap][cin][cout], bias [cout].
+struct ConvL {
+    size_t w, b;
+    int cin, cout;
+};
+struct EncStack {
+    std::vector<ConvL> conv;  // conv[0] at the stack's input resolution, the rest after the 2x max-pool
+    int H, W;                 // input resolution of the stack
+};
+struct EncNet {
+    std::vector<EncStack> stacks;
+    Layer dense;              // flat -> enc_dim
+    int flat = 0;
+    size_t off = 0, size = 0;
+};
+enum { ENC_C = 0, ENC_BC, ENC_OS, ENC_T, NUM_ENC };
+inline int pad16c(int c) { return (c + 15) & ~15; }
+
 struct Segment {  // one contiguous padded block of a leaf
     size_t off;
     int rows, cols, rows_p, cols_p;  // logical and padded 2-D shape (vectors: rows = 1)
@@ -92,7 +112,7 @@ struct Leaf {
 // program = ordered ops with read/write sets -> levels -> launches
 // ------------------------------------------------------------------------------------------------
 enum OpType { OP_GEMM, OP_GEMM64, OP_WGRAD, OP_LNBWD, OP_PREP, OP_POSTOS, OP_EULER_FIN, OP_PEC, OP_LOSS_CRITIC, OP_LOSS_Q, OP_LOSS_BC,
-              OP_LOSS_ACTOR, OP_ADAM, OP_FINALIZE };
+              OP_LOSS_ACTOR, OP_CONV, OP_POOL, OP_POOL_BWD, OP_CONV_WGRAD, OP_CONV_WRED, OP_ENC_DZ, OP_ADAM, OP_FINALIZE };
 
 struct Op {
     OpType type;
@@ -108,6 +128,13 @@ struct Op {
     LossActorArgs la;
     EulerFinishArgs ef;
     PecArgs pec;
+    ConvArgs conv;
+    PoolArgs pool;
+    PoolBwdArgs poolb;
+    ConvWgradArgs cw;
+    ConvWredArgs cwr;
+    EncDzArgs edz;
+    int cw_grid = 0;
     int adam_c0 = 0, adam_n = -1;  // chunk range of an Adam op (-1: all chunks)
     int fin_mode = 0;
     int level = 0;
@@ -154,6 +181,17 @@ struct PassBuf {
     float* dx0 = nullptr;
 };
 
+// activations of one encoder pass over n images (kept for the backward pass)
+struct EncBuf {
+    int enc = 0, n = 0;
+    const unsigned char* img = nullptr;
+    struct St { float *c0 = nullptr, *pool = nullptr; unsigned char* arg = nullptr; std::vector<float*> c1, y; };
+    std::vector<St> st;
+    float *frelu = nullptr, *z = nullptr, *E = nullptr;   // [n, flat], [n, enc_dim] x 2
+    // backward scratch (allocated only for differentiated passes)
+    float *dz = nullptr, *dA = nullptr, *dB = nullptr, *dC = nullptr, *wpart = nullptr;
+};
+
 }  // namespace
 
 struct fql_engine {
@@ -166,6 +204,11 @@ struct fql_engine {
     std::string err;
 
     Net nets[NUM_NETS];
+    EncNet encs[NUM_ENC];
+    bool visual = false;
+    int enc_dim = 0;
+    unsigned char* img_all = nullptr;   // [2B] images: obs batch, then next_obs batch (fixed address: graphs bake it in)
+    EncBuf eb_c, eb_t, eb_bc, eb_os;
     size_t n_train = 0, n_total = 0, critic_size = 0;
     float *P = nullptr, *G = nullptr, *Mu = nullptr, *Nu = nullptr;
     std::vector<Leaf> leaves;
@@ -263,6 +306,35 @@ struct fql_engine {
         nets[NET_T0] = nets[NET_C0];
         nets[NET_T1] = nets[NET_C0];
         size_t off = 0;
+        auto place_enc = [&](int ei) {
+            if (!visual) return;
+            EncNet& en = encs[ei];
+            en = EncNet{};
+            en.off = off;
+            const int sizes[3] = {16, 32, 32};  // impala_small: stack_sizes (16, 32, 32), num_blocks 1 (utils/encoders.py:66-67,106)
+            int H = cfg.img_h, W = cfg.img_w, cin = cfg.img_c;
+            for (int s = 0; s < 3; ++s) {
+                EncStack st;
+                st.H = H; st.W = W;
+                for (int j = 0; j < 3; ++j) {
+                    ConvL c{};
+                    c.cin = cin; c.cout = sizes[s];
+                    c.w = off; off += (size_t)9 * c.cin * c.cout;
+                    c.b = off; off += c.cout;
+                    st.conv.push_back(c);
+                    cin = sizes[s];
+                }
+                en.stacks.push_back(st);
+                H /= 2; W /= 2;
+            }
+            en.flat = H * W * cin;
+            Layer& D = en.dense;
+            D = Layer{};
+            D.in = D.in_p = en.flat; D.out = D.out_p = enc_dim; D.ln = false;
+            D.w = off; off += (size_t)D.in_p * D.out_p;
+            D.b = off; off += D.out_p;
+            en.size = off - en.off;
+        };
         for (int ni = 0; ni < NUM_NETS; ++ni) {
             Net& n = nets[ni];
             n.off = off;
@@ -275,28 +347,56 @@ struct fql_engine {
                 }
             }
             n.size = off - n.off;
-            if (ni == NET_C1) critic_size = off;
-            if (ni == NET_OS) n_train = off;
+            // every module's encoder follows its MLP(s); the critic's sits inside the Polyak-averaged region
+            if (ni == NET_C1) { place_enc(ENC_C); critic_size = off; }
+            if (ni == NET_BC) place_enc(ENC_BC);
+            if (ni == NET_OS) { place_enc(ENC_OS); n_train = off; }
+            if (ni == NET_T1) place_enc(ENC_T);
         }
         n_total = off;
         for (int ni = 0; ni < NUM_NETS; ++ni)
             for (const Layer& L : nets[ni].layers)
                 if (L.in_p > 1024 || L.out_p > 1024) invalid("layer widths above 1024 are not supported (got %d -> %d)", L.in, L.out);
-        if (nets[NET_T0].off - n_train != 0 || nets[NET_T0].size + nets[NET_T1].size != critic_size)
+        if (nets[NET_T0].off - n_train != 0 || nets[NET_T0].size + nets[NET_T1].size + (visual ? encs[ENC_T].size : 0) != critic_size)
             invalid("internal: target arena layout mismatch");
     }
 
     void build_leaves() {
         leaves.clear();
-        struct Mod { const char* name; const char* sub; int n0, n1; bool train; };
-        const Mod mods[4] = {{"modules_actor_bc_flow", "mlp", NET_BC, -1, true},
-                             {"modules_actor_onestep_flow", "mlp", NET_OS, -1, true},
-                             {"modules_critic", "value_net", NET_C0, NET_C1, true},
-                             {"modules_target_critic", "value_net", NET_T0, NET_T1, false}};
+        struct Mod { const char* name; const char* sub; int n0, n1; bool train; int enc; };
+        const Mod mods[4] = {{"modules_actor_bc_flow", "mlp", NET_BC, -1, true, ENC_BC},
+                             {"modules_actor_onestep_flow", "mlp", NET_OS, -1, true, ENC_OS},
+                             {"modules_critic", "value_net", NET_C0, NET_C1, true, ENC_C},
+                             {"modules_target_critic", "value_net", NET_T0, NET_T1, false, ENC_T}};
         int tid = 0;
         for (const Mod& m : mods) {
             const Net& n0 = nets[m.n0];
             const bool ens = m.n1 >= 0;
+            if (visual) {
+                // "<module>/encoder/..." sorts before "mlp" / "value_net"; inside: MLP_0 < stack_blocks_* (flax auto names,
+                // utils/encoders.py:72-79,98); the encoder is NOT ensembled (utils/networks.py:186-187: applied before value_net)
+                const EncNet& en = encs[m.enc];
+                auto add_plain = [&](const std::string& name, std::vector<int64_t> shape, size_t off, int rows, int cols) {
+                    Leaf lf;
+                    lf.name = name;
+                    lf.ndim = (int)shape.size();
+                    for (int k = 0; k < 4; ++k) lf.shape[k] = k < lf.ndim ? shape[k] : 1;
+                    lf.segs.push_back(Segment{off, rows, cols, rows, cols});
+                    lf.trainable = m.train;
+                    lf.train_id = m.train ? tid++ : -1;
+                    leaves.push_back(lf);
+                };
+                const std::string eb = std::string(m.name) + "/encoder/";
+                add_plain(eb + "MLP_0/Dense_0/bias", {en.dense.out}, en.dense.b, 1, en.dense.out);
+                add_plain(eb + "MLP_0/Dense_0/kernel", {en.dense.in, en.dense.out}, en.dense.w, en.dense.in, en.dense.out);
+                for (size_t s = 0; s < en.stacks.size(); ++s)
+                    for (size_t j = 0; j < en.stacks[s].conv.size(); ++j) {
+                        const ConvL& c = en.stacks[s].conv[j];
+                        const std::string cb = eb + "stack_blocks_" + std::to_string(s) + "/Conv_" + std::to_string(j);
+                        add_plain(cb + "/bias", {c.cout}, c.b, 1, c.cout);
+                        add_plain(cb + "/kernel", {3, 3, c.cin, c.cout}, c.w, 9 * c.cin, c.cout);
+                    }
+            }
             auto add = [&](const std::string& name, bool matrix, int rows, int cols, size_t o0, size_t o1, int rp, int cp) {
                 Leaf lf;
                 lf.name = name;
@@ -398,6 +498,20 @@ struct fql_engine {
                 if (L.ln)
                     for (int c = 0; c < L.out; ++c) h[L.g + c] = 1.0f;
             }
+        if (visual)
+            for (int ei = 0; ei <= ENC_OS; ++ei) {   // xavier_uniform convolutions (utils/encoders.py:18), Glorot Dense, zero biases
+                const EncNet& en = encs[ei];
+                for (const EncStack& st : en.stacks)
+                    for (const ConvL& c : st.conv) {
+                        const double lim = std::sqrt(6.0 / (9.0 * c.cin + 9.0 * c.cout));
+                        std::uniform_real_distribution<double> U(-lim, lim);
+                        for (size_t i = 0; i < (size_t)9 * c.cin * c.cout; ++i) h[c.w + i] = (float)U(gen);
+                    }
+                const Layer& D = en.dense;
+                const double lim = std::sqrt(6.0 / (double)(D.in + D.out));
+                std::uniform_real_distribution<double> U(-lim, lim);
+                for (size_t i = 0; i < (size_t)D.in * D.out; ++i) h[D.w + i] = (float)U(gen);
+            }
         std::memcpy(h.data() + n_train, h.data(), critic_size * sizeof(float));
         HIP_CHECK(hipMemcpy(P, h.data(), n_total * sizeof(float), hipMemcpyHostToDevice));
     }
@@ -431,6 +545,223 @@ struct fql_engine {
             if (input_grad) p.dx0 = dalloc(owner, (size_t)M * n.in_p());
         }
         return p;
+    }
+
+    // ---------------------------------------------------------------------------------------
+    // visual path: encoder passes (utils/encoders.py:61-100) as conv / pool / GEMM ops of the same program
+    // ---------------------------------------------------------------------------------------
+    EncBuf make_enc_buf(std::vector<void*>& owner, int enc, int n, const unsigned char* img, bool bwd) {
+        const EncNet& en = encs[enc];
+        EncBuf b;
+        b.enc = enc; b.n = n; b.img = img;
+        size_t maxel = 0;
+        for (const EncStack& st : en.stacks) {
+            EncBuf::St s;
+            const int C = st.conv[0].cout;
+            const size_t full = (size_t)n * st.H * st.W * C, quarter = full / 4;
+            maxel = std::max(maxel, full);
+            s.c0 = dalloc(owner, full);
+            s.pool = dalloc(owner, quarter);
+            s.arg = (unsigned char*)dalloc(owner, quarter / 4 + 4);
+            for (size_t j = 1; j + 1 < st.conv.size(); j += 2) {
+                s.c1.push_back(dalloc(owner, quarter));
+                s.y.push_back(dalloc(owner, quarter));
+            }
+            b.st.push_back(s);
+        }
+        b.frelu = dalloc(owner, (size_t)n * en.flat);
+        b.z = dalloc(owner, (size_t)n * enc_dim);
+        b.E = dalloc(owner, (size_t)n * enc_dim);
+        if (bwd) {
+            b.dz = dalloc(owner, (size_t)n * enc_dim);
+            b.dA = dalloc(owner, maxel); b.dB = dalloc(owner, maxel); b.dC = dalloc(owner, maxel);
+            b.wpart = dalloc(owner, (size_t)1024 * (9 * 32 + 1) * 32);
+        }
+        return b;
+    }
+    // image rows per workgroup: <= 8 MFMA row tiles of 16 pixels, whole rows, LDS within 64 KB
+    static int conv_rows(int H, int W, int Ci, int Co, bool wgrad) {
+        for (int R = std::min(H, std::max(1, 128 / W)); R >= 1; R >>= 1) {
+            if (H % R || (R * W) % 16) continue;
+            const size_t fl = wgrad ? (size_t)(R + 2) * (W + 2) * (Ci + 4) + (size_t)R * W * (Co + 4)
+                                    : (size_t)(R + 2) * (W + 2) * (Ci + 4) + (size_t)Co * (9 * Ci + 4);
+            if (fl * sizeof(float) <= 65536) return R;
+        }
+        invalid("convolution tile does not fit (H %d, W %d, channels %d -> %d)", H, W, Ci, Co);
+    }
+    void emit_conv(Program& pr, const void* in, const void* in_id, int in_mode, int n, int H, int W, const ConvL& c, bool transposed,
+                   float* out, const void* out_id, float* out_relu, const float* mask, const void* mask_id, const float* add, const void* add_id) {
+        Op op{};
+        op.type = OP_CONV;
+        ConvArgs& a = op.conv;
+        a.in = in; a.Wt = P + c.w; a.bias = transposed ? nullptr : P + c.b;
+        a.out = out; a.out_relu = out_relu; a.mask = mask; a.add = add;
+        a.N = n; a.H = H; a.W = W;
+        if (!transposed) { a.Ci = pad16c(c.cin); a.Ci_real = c.cin; a.Co = c.cout; }
+        else { a.Ci = c.cout; a.Ci_real = c.cout; a.Co = c.cin; }
+        a.in_mode = in_mode; a.transposed = transposed ? 1 : 0;
+        a.Cw_rows = c.cin; a.Cw_cols = c.cout;
+        a.R = conv_rows(H, W, a.Ci, a.Co, false);
+        op.reads = {in_id, P + c.w};
+        if (mask) op.reads.push_back(mask_id);
+        if (add) op.reads.push_back(add_id);
+        op.writes = {out_id};
+        if (out_relu) op.writes.push_back(out_relu);
+        push(pr, op);
+    }
+    void emit_encoder_forward(Program& pr, EncBuf& b) {
+        const EncNet& en = encs[b.enc];
+        const int n = b.n;
+        const float* x = nullptr;
+        for (size_t s = 0; s < en.stacks.size(); ++s) {
+            const EncStack& st = en.stacks[s];
+            EncBuf::St& bs = b.st[s];
+            const int C = st.conv[0].cout, H2 = st.H / 2, W2 = st.W / 2;
+            if (s == 0) emit_conv(pr, b.img, b.img, 2, n, st.H, st.W, st.conv[0], false, bs.c0, bs.c0, nullptr, nullptr, nullptr, nullptr, nullptr);
+            else emit_conv(pr, x, x, 0, n, st.H, st.W, st.conv[0], false, bs.c0, bs.c0, nullptr, nullptr, nullptr, nullptr, nullptr);
+            {
+                Op op{};
+                op.type = OP_POOL;
+                op.pool = PoolArgs{bs.c0, bs.pool, bs.arg, n, st.H, st.W, C};
+                op.reads = {bs.c0};
+                op.writes = {bs.pool, bs.arg};
+                push(pr, op);
+            }
+            const float* y = bs.pool;
+            for (size_t blk = 0; blk < bs.c1.size(); ++blk) {
+                const bool last = s + 1 == en.stacks.size() && blk + 1 == bs.c1.size();
+                emit_conv(pr, y, y, 1, n, H2, W2, st.conv[1 + 2 * blk], false, bs.c1[blk], bs.c1[blk], nullptr, nullptr, nullptr, nullptr, nullptr);
+                emit_conv(pr, bs.c1[blk], bs.c1[blk], 1, n, H2, W2, st.conv[2 + 2 * blk], false, bs.y[blk], bs.y[blk], last ? b.frelu : nullptr,
+                          nullptr, nullptr, y, y);
+                y = bs.y[blk];
+            }
+            x = y;
+        }
+        Op op{};   // MLP((512,), activate_final=True): Dense + GELU (utils/encoders.py:98)
+        op.type = OP_GEMM;
+        GemmTask& t = op.gemm;
+        const Layer& D = en.dense;
+        t.A = b.frelu; t.lda = D.in_p;
+        t.B = P + D.w; t.ldb = D.out_p; t.bias = P + D.b;
+        t.C = b.E; t.ldc = D.out_p; t.Zout = b.z;
+        t.M = n; t.N = D.out_p; t.K = D.in_p;
+        t.flags = GF_BIAS | GF_GELU | GF_SAVE_Z;
+        op.reads = {t.A, t.B};
+        op.writes = {t.C, t.Zout};
+        if (want64(t.M, t.N, t.K, t.flags)) op.type = OP_GEMM64;
+        else if (t.K > 1024) invalid("encoder Dense with %d inputs needs a batch that is a multiple of 64", t.K);
+        push(pr, op);
+    }
+    void emit_conv_wgrad(Program& pr, EncBuf& b, const void* in, const void* in_id, int in_mode, int n, int H, int W, const ConvL& c,
+                         const float* dout, const void* dout_id) {
+        Op op{};
+        op.type = OP_CONV_WGRAD;
+        ConvWgradArgs& a = op.cw;
+        a.in = in; a.dout = dout; a.partial = b.wpart;
+        a.N = n; a.H = H; a.W = W; a.Ci = pad16c(c.cin); a.Ci_real = c.cin; a.Co = c.cout; a.in_mode = in_mode;
+        a.R = conv_rows(H, W, a.Ci, a.Co, true);
+        a.nblocks = n * (H / a.R);
+        op.cw_grid = std::min(a.nblocks, 256);
+        op.reads = {in_id, dout_id};
+        op.writes = {b.wpart};
+        push(pr, op);
+        Op r{};
+        r.type = OP_CONV_WRED;
+        r.cwr = ConvWredArgs{b.wpart, G + c.w, G + c.b, op.cw_grid * 4, a.Ci, a.Co, c.cin};
+        r.reads = {b.wpart};
+        r.writes = {G + c.w, G + c.b};
+        push(pr, r);
+    }
+    // backward of images [img0, img0 + n) of pass b; the encoding's gradient = first enc_dim columns of dxa (+ dxb)
+    void emit_encoder_backward(Program& pr, EncBuf& b, int img0, int n, const float* dxa, const float* dxb, int ld) {
+        const EncNet& en = encs[b.enc];
+        const Layer& D = en.dense;
+        {
+            Op op{};
+            op.type = OP_ENC_DZ;
+            op.edz = EncDzArgs{dxa, dxb, b.z + (size_t)img0 * enc_dim, b.dz, n, enc_dim, ld};
+            op.reads = {dxa, b.z};
+            if (dxb) op.reads.push_back(dxb);
+            op.writes = {b.dz};
+            push(pr, op);
+        }
+        {
+            Op op{};
+            op.type = OP_WGRAD;
+            WgradTask& w = op.wgrad;
+            w.X = b.frelu + (size_t)img0 * en.flat; w.ldx = D.in_p;
+            w.dZ = b.dz; w.ldz = D.out_p;
+            w.dW = G + D.w; w.ldw = D.out_p; w.db = G + D.b;
+            w.M = n; w.Kin = D.in_p; w.N = D.out_p;
+            op.reads = {b.frelu, b.dz};
+            op.writes = {w.dW, w.db};
+            push(pr, op);
+        }
+        const EncStack& lst = en.stacks.back();
+        const float* xfinal = b.st.back().y.empty() ? b.st.back().pool : b.st.back().y.back();
+        {
+            Op op{};   // d(flat) = dz W^T, through the final ReLU (utils/encoders.py:92)
+            op.type = OP_GEMM;
+            GemmTask& t = op.gemm;
+            t.A = b.dz; t.lda = D.out_p;
+            t.B = P + D.w; t.ldb = D.out_p;
+            t.C = b.dA; t.ldc = D.in_p;
+            t.M = n; t.N = D.in_p; t.K = D.out_p;
+            t.flags = GF_TRANS_B | GF_RELUGRAD;
+            t.Zprev = xfinal + (size_t)img0 * en.flat;
+            op.reads = {b.dz, t.B, xfinal};
+            op.writes = {b.dA};
+            if (want64(t.M, t.N, t.K, t.flags)) op.type = OP_GEMM64;
+            push(pr, op);
+        }
+        (void)lst;
+        float* dy = b.dA;
+        std::vector<float*> freeb = {b.dB, b.dC};
+        auto take = [&]() { float* p = freeb.back(); freeb.pop_back(); return p; };
+        for (int s = (int)en.stacks.size() - 1; s >= 0; --s) {
+            const EncStack& st = en.stacks[s];
+            EncBuf::St& bs = b.st[s];
+            const int C = st.conv[0].cout, H2 = st.H / 2, W2 = st.W / 2;
+            const size_t q_img = (size_t)H2 * W2 * C, f_img = (size_t)st.H * st.W * C;
+            for (int blk = (int)bs.c1.size() - 1; blk >= 0; --blk) {
+                const float* inp = blk == 0 ? bs.pool : bs.y[blk - 1];
+                const float* c1 = bs.c1[blk];
+                const float* inp_o = inp + (size_t)img0 * q_img;
+                const float* c1_o = c1 + (size_t)img0 * q_img;
+                emit_conv_wgrad(pr, b, c1_o, c1, 1, n, H2, W2, st.conv[2 + 2 * blk], dy, dy);
+                float* d_c1 = take();
+                emit_conv(pr, dy, dy, 0, n, H2, W2, st.conv[2 + 2 * blk], true, d_c1, d_c1, nullptr, c1_o, c1, nullptr, nullptr);
+                emit_conv_wgrad(pr, b, inp_o, inp, 1, n, H2, W2, st.conv[1 + 2 * blk], d_c1, d_c1);
+                float* dy_new = take();
+                emit_conv(pr, d_c1, d_c1, 0, n, H2, W2, st.conv[1 + 2 * blk], true, dy_new, dy_new, nullptr, inp_o, inp, dy, dy);
+                freeb.push_back(d_c1); freeb.push_back(dy);
+                dy = dy_new;
+            }
+            float* d_c0 = take();
+            {
+                Op op{};
+                op.type = OP_POOL_BWD;
+                op.poolb = PoolBwdArgs{dy, bs.arg + (size_t)img0 * q_img, d_c0, n, st.H, st.W, C};
+                op.reads = {dy, bs.arg};
+                op.writes = {d_c0};
+                push(pr, op);
+            }
+            if (s == 0) {
+                const size_t ib = (size_t)st.H * st.W * st.conv[0].cin;
+                emit_conv_wgrad(pr, b, b.img + (size_t)img0 * ib, b.img, 2, n, st.H, st.W, st.conv[0], d_c0, d_c0);
+            } else {
+                const EncBuf::St& ps = b.st[s - 1];
+                const float* xin = ps.y.empty() ? ps.pool : ps.y.back();
+                const size_t xi = (size_t)st.H * st.W * st.conv[0].cin;
+                emit_conv_wgrad(pr, b, xin + (size_t)img0 * xi, xin, 0, n, st.H, st.W, st.conv[0], d_c0, d_c0);
+                float* dprev = take();
+                emit_conv(pr, d_c0, d_c0, 0, n, st.H, st.W, st.conv[0], true, dprev, dprev, nullptr, nullptr, nullptr, nullptr, nullptr);
+                freeb.push_back(dy);
+                dy = dprev;
+            }
+            freeb.push_back(d_c0);
+            (void)f_img;
+        }
     }
 
     // throughput-lane tasks with 64-aligned shapes go to the 64x64 LDS-tiled kernel
@@ -1047,6 +1378,41 @@ struct fql_engine {
                 case OP_LOSS_ACTOR:
                     hipLaunchKernelGGL(fql_loss_actor_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.la);
                     break;
+                case OP_CONV: {
+                    const ConvArgs& a = L.op.conv;
+                    const size_t lds = ((size_t)(a.R + 2) * (a.W + 2) * (a.Ci + 4) + (size_t)a.Co * (9 * a.Ci + 4)) * sizeof(float);
+                    hipLaunchKernelGGL(fql_conv3x3_kernel, dim3(a.N * (a.H / a.R)), dim3(FQL_THREADS), lds, s, a);
+                    break;
+                }
+                case OP_POOL: {
+                    const PoolArgs& a = L.op.pool;
+                    const size_t tot = (size_t)a.N * (a.H / 2) * (a.W / 2) * (a.C / 4);
+                    hipLaunchKernelGGL(fql_maxpool_kernel, dim3((unsigned)((tot + FQL_THREADS - 1) / FQL_THREADS)), dim3(FQL_THREADS), 0, s, a);
+                    break;
+                }
+                case OP_POOL_BWD: {
+                    const PoolBwdArgs& a = L.op.poolb;
+                    const size_t tot = (size_t)a.N * a.H * a.W * (a.C / 4);
+                    hipLaunchKernelGGL(fql_maxpool_bwd_kernel, dim3((unsigned)((tot + FQL_THREADS - 1) / FQL_THREADS)), dim3(FQL_THREADS), 0, s, a);
+                    break;
+                }
+                case OP_CONV_WGRAD: {
+                    const ConvWgradArgs& a = L.op.cw;
+                    const size_t lds = ((size_t)(a.R + 2) * (a.W + 2) * (a.Ci + 4) + (size_t)a.R * a.W * (a.Co + 4)) * sizeof(float);
+                    hipLaunchKernelGGL(fql_conv_wgrad_kernel, dim3(L.op.cw_grid), dim3(FQL_THREADS), lds, s, a);
+                    break;
+                }
+                case OP_CONV_WRED: {
+                    const ConvWredArgs& a = L.op.cwr;
+                    const int tot = (9 * a.Ci + 1) * a.Co;
+                    hipLaunchKernelGGL(fql_conv_wgrad_reduce_kernel, dim3((tot + FQL_THREADS - 1) / FQL_THREADS), dim3(FQL_THREADS), 0, s, a);
+                    break;
+                }
+                case OP_ENC_DZ: {
+                    const EncDzArgs& a = L.op.edz;
+                    hipLaunchKernelGGL(fql_enc_dz_kernel, dim3((a.M * a.n + FQL_THREADS - 1) / FQL_THREADS), dim3(FQL_THREADS), 0, s, a);
+                    break;
+                }
                 case OP_ADAM: {
                     AdamArgs a{P, G, Mu, Nu, P + n_train, d_chunks, d_state, d_partials, L.op.adam_c0, (int)critic_size, cfg.lr, cfg.tau};
                     hipLaunchKernelGGL(fql_adam_kernel, dim3(L.op.adam_n < 0 ? n_chunks : L.op.adam_n), dim3(FQL_THREADS), 0, s, a);
@@ -1171,14 +1537,25 @@ struct fql_engine {
         const void *I_CR = &st->info[0], *I_BC = &st->info[5], *I_Q = &st->info[7], *I_MSE = &st->info[9], *I_ACT = &st->info[4];
         // Lane 0 carries the critical path (prep -> Euler chain -> actor loss -> one-step backward); the rest of
         // the step runs beside it on lane 1 (a second graph branch) and only meets it at the actor loss.
+        if (visual) {   // every module encodes the batch images first (agents/fql.py:196-202); the encodings feed prep
+            place("enc", 1, true);
+            emit_encoder_forward(pr, eb_os);   // [obs ; next_obs]: sample_actions(next_obs) fql.py:25, onestep(obs) fql.py:65,82
+            emit_encoder_forward(pr, eb_c);    // critic(obs, .) fql.py:36,70 (same stored encoder and images: one pass)
+            emit_encoder_forward(pr, eb_t);    // target_critic(next_obs, .) fql.py:28
+            emit_encoder_forward(pr, eb_bc);   // actor_bc_flow(obs, .) fql.py:58 and actor_bc_flow_encoder(obs) fql.py:163 (shared)
+        }
         emit_lane = 0;
         {   // batch gather + noise + every network input
             Op op{};
             op.type = OP_PREP;
             op.prep = PrepArgs{d_src, st, seed, B, od, ad, inp_c, inp_b, ap, X_os, X_bc, X_eu, X_c1, X_c2, X_ct, vel, w_rew, w_mask, w_act,
-                               fused_euler ? X_e0 : nullptr};
+                               fused_euler ? X_e0 : nullptr, nullptr, nullptr, nullptr, nullptr};
             op.writes = {X_os, X_bc, X_eu, X_c1, X_c2, X_ct, vel, w_rew, w_mask, w_act};
             if (fused_euler) op.writes.push_back(X_e0);
+            if (visual) {
+                op.prep.E_c = eb_c.E; op.prep.E_t = eb_t.E; op.prep.E_bc = eb_bc.E; op.prep.E_os = eb_os.E;
+                op.reads = {eb_c.E, eb_t.E, eb_bc.E, eb_os.E};
+            }
             push(pr, op);
         }
         place("os", 1, true);
@@ -1210,7 +1587,11 @@ struct fql_engine {
             push(pr, op);
         }
         if (with_grads)
-            for (int e = 0; e < 2; ++e) emit_backward(pr, p_c1[e], 0, B, true, false);
+            for (int e = 0; e < 2; ++e) emit_backward(pr, p_c1[e], 0, B, true, visual);
+        if (with_grads && visual) {   // the critic's encoder sees the critic loss only (the actor loss uses stored params)
+            place("enc", 1, true);
+            emit_encoder_backward(pr, eb_c, 0, B, p_c1[0].dx0, p_c1[1].dx0, nets[NET_C0].in_p());
+        }
         // BC flow-matching pass (fql.py:52-59)
         place("bc", 1, true);
         emit_forward(pr, p_bc, with_grads);
@@ -1223,7 +1604,11 @@ struct fql_engine {
             if (with_grads) op.writes.push_back(p_bc.dz.back());
             push(pr, op);
         }
-        if (with_grads) emit_backward(pr, p_bc, 0, B, true, false);
+        if (with_grads) emit_backward(pr, p_bc, 0, B, true, visual);
+        if (with_grads && visual) {
+            place("enc", 1, true);
+            emit_encoder_backward(pr, eb_bc, 0, B, p_bc.dx0, nullptr, nets[NET_BC].in_p());
+        }
         // Q term: critic(obs, clip(actor_actions)) with stored params, input-differentiable (fql.py:69-76)
         place("c2", 1, true);
         for (int e = 0; e < 2; ++e) emit_forward(pr, p_c2[e], with_grads);
@@ -1265,7 +1650,11 @@ struct fql_engine {
             }
             push(pr, op);
         }
-        if (with_grads) emit_backward(pr, p_os_bwd, B, B, true, false);
+        if (with_grads) emit_backward(pr, p_os_bwd, B, B, true, visual);
+        if (with_grads && visual) {   // the obs half of the [obs ; next_obs] pass
+            place("enc", 1, true);
+            emit_encoder_backward(pr, eb_os, 0, B, p_os_bwd.dx0, nullptr, nets[NET_OS].in_p());
+        }
         if (!with_grads) {
             Op op{};
             op.type = OP_FINALIZE;
@@ -1304,6 +1693,19 @@ struct fql_engine {
             a.adam_c0 = mod_chunk0[m]; a.adam_n = mod_chunkn[m];
             a.reads = {st};
             a.writes = {d_partials + mod_chunk0[m] * 4};
+            if (visual) {
+                const int ei = m == 2 ? ENC_C : (m == 0 ? ENC_BC : ENC_OS);
+                for (const EncStack& st : encs[ei].stacks)
+                    for (const ConvL& c : st.conv) {
+                        a.reads.push_back(G + c.w); a.reads.push_back(G + c.b);
+                        a.writes.push_back(P + c.w);
+                        if (m == 2) a.writes.push_back(P + n_train + c.w);
+                    }
+                const Layer& D = encs[ei].dense;
+                a.reads.push_back(G + D.w); a.reads.push_back(G + D.b);
+                a.writes.push_back(P + D.w);
+                if (m == 2) a.writes.push_back(P + n_train + D.w);
+            }
             for (int ni : net_ids)
                 for (const Layer& L : nets[ni].layers) {
                     a.reads.push_back(G + L.w); a.reads.push_back(G + L.b);
@@ -1393,6 +1795,14 @@ struct fql_engine {
                 }
             }
         }
+        if (visual) {
+            const size_t ib = (size_t)cfg.img_h * cfg.img_w * cfg.img_c;
+            img_all = (unsigned char*)dalloc(W, (2 * (size_t)B * ib + 3) / 4 + 4);
+            eb_os = make_enc_buf(W, ENC_OS, 2 * B, img_all, true);
+            eb_c = make_enc_buf(W, ENC_C, B, img_all, true);
+            eb_t = make_enc_buf(W, ENC_T, B, img_all + (size_t)B * ib, false);
+            eb_bc = make_enc_buf(W, ENC_BC, B, img_all, true);
+        }
         p_os = make_pass(W, NET_OS, 3 * B, X_os, false, false);
         {   // backward view of the (obs, z) block: own gradient buffers, forward buffers shared with p_os
             p_os_bwd = p_os;
@@ -1400,11 +1810,12 @@ struct fql_engine {
             const Net& n = nets[NET_OS];
             for (int l = 0; l < n.nl(); ++l) p_os_bwd.dz.push_back(dalloc(W, (size_t)B * n.layers[l].out_p));
             for (int l = 0; l + 1 < n.nl(); ++l) p_os_bwd.dy.push_back(n.layers[l].ln ? dalloc(W, (size_t)B * n.layers[l].out_p) : nullptr);
+            if (visual) p_os_bwd.dx0 = dalloc(W, (size_t)B * n.in_p());
         }
-        p_bc = make_pass(W, NET_BC, B, X_bc, true, false);
+        p_bc = make_pass(W, NET_BC, B, X_bc, true, visual);
         p_eu = make_pass(W, NET_BC, B, X_eu, false, false);
         for (int e = 0; e < 2; ++e) {
-            p_c1[e] = make_pass(W, NET_C0 + e, B, X_c1, true, false);
+            p_c1[e] = make_pass(W, NET_C0 + e, B, X_c1, true, visual);
             p_c2[e] = make_pass(W, NET_C0 + e, B, X_c2, true, true);
             p_ct[e] = make_pass(W, NET_T0 + e, B, X_ct, false, false);
         }
@@ -1471,11 +1882,18 @@ struct fql_engine {
         if (!obs || !act || !rew || !mask || !nobs) invalid("batch pointers must not be NULL");
         const int od = cfg.obs_dim, ad = cfg.act_dim;
         SrcDesc d{};
-        d.obs = stage(obs, in_obs, (size_t)B * od, s);
+        if (visual) {   // uint8 [B, H, W, C] batches into the fixed image buffer the encoder launches read: [obs ; next_obs]
+            const size_t ib = (size_t)cfg.img_h * cfg.img_w * cfg.img_c;
+            HIP_CHECK(hipMemcpyAsync(img_all, obs, (size_t)B * ib, hipMemcpyDefault, s));
+            HIP_CHECK(hipMemcpyAsync(img_all + (size_t)B * ib, nobs, (size_t)B * ib, hipMemcpyDefault, s));
+            if (!is_device_ptr(obs) || !is_device_ptr(nobs)) staged_host = true;
+        } else {
+            d.obs = stage(obs, in_obs, (size_t)B * od, s);
+            d.nobs = stage(nobs, in_nobs, (size_t)B * od, s);
+        }
         d.act = stage(act, in_act, (size_t)B * ad, s);
         d.rew = stage(rew, in_rew, B, s);
         d.mask = stage(mask, in_mask, B, s);
-        d.nobs = stage(nobs, in_nobs, (size_t)B * od, s);
         fill_noise(d, nz, s);
         d.advance = advance;
         drain_staging(s);
@@ -1633,6 +2051,16 @@ int fql_create(const fql_config* cfg, uint64_t seed, fql_handle* out) {
     try {
         h->cfg = *cfg;
         h->seed = seed;
+        if (cfg->encoder != 0) {   // visual agent (agents/fql.py:196-202): the MLPs see the 512-wide encoding instead of obs
+            if (cfg->encoder != 1) invalid("encoder %d not available (0 = none, 1 = impala_small)", cfg->encoder);
+            if (cfg->img_h <= 0 || cfg->img_w <= 0 || cfg->img_h % 32 || cfg->img_w % 32 || cfg->img_w > 128 || cfg->img_c <= 0 || cfg->img_c > 16)
+                invalid("image shape must be [H, W, C] with H, W multiples of 32 (W <= 128) and C <= 16 (got %d, %d, %d)", cfg->img_h,
+                        cfg->img_w, cfg->img_c);
+            h->visual = true;
+            h->enc_dim = 512;          // mlp_hidden_dims = (512,) (utils/encoders.py:69)
+            h->cfg.obs_dim = h->enc_dim;
+            cfg = &h->cfg;
+        }
         if (cfg->obs_dim <= 0 || cfg->act_dim <= 0) invalid("obs_dim and act_dim must be positive (got %d, %d)", cfg->obs_dim, cfg->act_dim);
         if (cfg->num_actor_hidden < 1 || cfg->num_actor_hidden > FQL_MAX_HIDDEN || cfg->num_value_hidden < 1 || cfg->num_value_hidden > FQL_MAX_HIDDEN)
             invalid("hidden layer counts must be in [1, %d]", FQL_MAX_HIDDEN);
@@ -1993,3 +2421,27 @@ int fql_stats(fql_handle h, int64_t* launches_per_update, int64_t* macs_per_upda
 void* fql_stream(fql_handle h) { return h ? (void*)h->stream : nullptr; }
 
 }  // extern "C"
+
+// Diagnostic only (not in include/fql_amd.h): copy an encoder-pass buffer to the host.  enc: 0 critic, 1 bc_flow, 2 onestep, 3 target;
+// code: 100 s + {0: c0, 1: pool, 2: c1[0], 3: y[0], 4: arg (bytes)}, 900: frelu, 901: z, 902: E, 903: dz, 904: dA, 905: dB, 906: dC
+extern "C" int fql_debug_enc(fql_handle h, int enc, int code, void* out, size_t bytes) {
+    if (!h || !h->visual) return FQL_E_INVALID;
+    EncBuf* b = enc == 0 ? &h->eb_c : enc == 1 ? &h->eb_bc : enc == 2 ? &h->eb_os : &h->eb_t;
+    const void* src = nullptr;
+    if (code >= 900) {
+        const void* tab[] = {b->frelu, b->z, b->E, b->dz, b->dA, b->dB, b->dC};
+        src = tab[code - 900];
+    } else {
+        EncBuf::St& s = b->st[code / 100];
+        switch (code % 100) {
+            case 0: src = s.c0; break;
+            case 1: src = s.pool; break;
+            case 2: src = s.c1[0]; break;
+            case 3: src = s.y[0]; break;
+            default: src = s.arg; break;
+        }
+    }
+    if (!src) return FQL_E_NOTFOUND;
+    hipDeviceSynchronize();
+    return hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? FQL_OK : FQL_E_HIP;
+}

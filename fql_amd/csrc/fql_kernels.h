@@ -40,6 +40,7 @@ enum : int {
     GF_A_EULER0 = 1 << 11,  // fused Euler step, part 1: A tile = GELU(C0 + a W0[act rows] + t W0[t row]) built in LDS
     GF_HEAD_PART = 1 << 12, // fused Euler step, part 3: epilogue multiplies the GELU tile into the action head (partials)
     GF_OS_SCATTER = 1 << 13, // one-step head on [next_obs; obs; obs] rows: also write clip(out) into the critic inputs
+    GF_RELUGRAD = 1 << 14,   // epilogue: C = (Zprev > 0) ? acc : 0  (dgrad through the encoder's final ReLU, utils/encoders.py:92)
     GF_LN_PART = 1 << 10,   // gemm64 epilogue: per-row (sum, sum sq) of this 64-column tile -> aux[row][i1 tiles][2]
 };
 
@@ -554,6 +555,7 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
         if (flags & GF_SAVE_Z) stg(T.Zout + o, v);
         if (flags & GF_GELU) v = gelu_f(v);
         if (flags & GF_GELUGRAD) v *= gelu_grad_f(ldg(T.Zprev + o));
+        if (flags & GF_RELUGRAD) v = (ldg(T.Zprev + o) > 0.f) ? v : 0.f;
         if (flags & GF_CLIP_OUT) v = clip1(v);
         stg(T.C + o, v);
         if ((flags & GF_OS_SCATTER) && n < T.i2) {
@@ -771,6 +773,8 @@ __device__ __forceinline__ void gemm64_body(const GemmTask& T, float* lds) {
                 if (flags & GF_SAVE_Z) stg(T.Zout + o, v);
                 if (flags & GF_GELU) v = gelu_f(v);
                 if (flags & GF_GELUGRAD) v *= gelu_grad_f(ldg(T.Zprev + o));
+                if (flags & GF_RELUGRAD) v = (ldg(T.Zprev + o) > 0.f) ? v : 0.f;
+        if (flags & GF_RELUGRAD) v = (ldg(T.Zprev + o) > 0.f) ? v : 0.f;
                 stg(T.C + o, v);
                 s1[i][r] += v; s2[i][r] += v * v;
             }
@@ -1028,6 +1032,9 @@ struct PrepArgs {
     int ap;            // padded action width (ld of the [B, ap] action-shaped buffers)
     float *X_os, *X_bc, *X_eu, *X_c1, *X_c2, *X_ct, *vel, *w_rew, *w_mask, *w_act;
     float* X_e0;  // [B, inp_b] observations only (fused Euler chain: loop-invariant part of layer 0) or null
+    // visual agents: the "observation" block of each network input is that module's encoding of the batch images
+    // (agents/fql.py:196-202; [B, od] each, row b = batch row b; E_os holds [obs ; next_obs] = 2B rows); null otherwise
+    const float *E_c, *E_t, *E_bc, *E_os;
 };
 
 // agents/fql.py:52-56 (x_t, vel), :144-150 (noise), utils/datasets.py:64-100 (index draw + gather),
@@ -1042,8 +1049,9 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_prep_kernel(PrepArgs P) {
     if (S.idx) src = S.idx[b];
     else if (S.use_rng_idx) src = S.lo + (int64_t)(((uint64_t)rng_u32(P.key, step, 7u, (uint32_t)b) * (uint64_t)S.span) >> 32);
     const int od = P.od, ad = P.ad, B = P.B;
-    const float* obs = S.obs + (size_t)src * od;
-    const float* nobs = S.nobs + (size_t)src * od;
+    const bool vis = P.E_c != nullptr;
+    const float* obs = vis ? nullptr : S.obs + (size_t)src * od;
+    const float* nobs = vis ? nullptr : S.nobs + (size_t)src * od;
     const float* act = S.act + (size_t)src * ad;
     const float tt = S.t ? S.t[b] : rng_uniform(P.key, step, 3u, (uint32_t)b);
     const int maxw = P.inp_c > P.inp_b ? P.inp_c : P.inp_b;
@@ -1051,7 +1059,14 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_prep_kernel(PrepArgs P) {
         const bool is_obs = j < od, is_act = (j >= od) && (j < od + ad);
         const int a = j - od;
         float o = 0.f, no = 0.f, av = 0.f, e1 = 0.f, e2 = 0.f, zz = 0.f, xx = 0.f;
-        if (is_obs) { o = obs[j]; no = nobs[j]; }
+        float o_c, o_bc, o_os, no_os, no_t;  // per consumer: critic(obs), bc_flow(obs), onestep(obs), onestep(next), target(next)
+        if (is_obs && !vis) { o = obs[j]; no = nobs[j]; }
+        o_c = o_bc = o_os = o; no_os = no_t = no;
+        if (is_obs && vis) {
+            const size_t r = (size_t)b * od + j;
+            o_c = P.E_c[r]; o_bc = P.E_bc[r]; no_t = P.E_t[r];
+            o_os = P.E_os[r]; no_os = P.E_os[(size_t)B * od + r];
+        }
         if (is_act) {
             av = act[a];
             e1 = S.eps1 ? S.eps1[(size_t)b * ad + a] : rng_normal(P.key, step, 1u, (uint32_t)b, (uint32_t)a);
@@ -1061,19 +1076,19 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_prep_kernel(PrepArgs P) {
         }
         if (j < P.inp_c) {
             const size_t w = P.inp_c;
-            P.X_os[(size_t)b * w + j] = is_obs ? no : e1;            // sample_actions(next_obs)  fql.py:25
-            P.X_os[(size_t)(B + b) * w + j] = is_obs ? o : zz;       // onestep(obs, noises)      fql.py:65
-            P.X_os[(size_t)(2 * B + b) * w + j] = is_obs ? o : e2;   // sample_actions(obs)       fql.py:82
-            P.X_c1[(size_t)b * w + j] = is_obs ? o : av;             // critic(obs, actions)      fql.py:36
-            P.X_c2[(size_t)b * w + j] = is_obs ? o : 0.f;            // action block filled after onestep
-            P.X_ct[(size_t)b * w + j] = is_obs ? no : 0.f;
+            P.X_os[(size_t)b * w + j] = is_obs ? no_os : e1;         // sample_actions(next_obs)  fql.py:25
+            P.X_os[(size_t)(B + b) * w + j] = is_obs ? o_os : zz;    // onestep(obs, noises)      fql.py:65
+            P.X_os[(size_t)(2 * B + b) * w + j] = is_obs ? o_os : e2;  // sample_actions(obs)     fql.py:82
+            P.X_c1[(size_t)b * w + j] = is_obs ? o_c : av;           // critic(obs, actions)      fql.py:36
+            P.X_c2[(size_t)b * w + j] = is_obs ? o_c : 0.f;          // action block filled after onestep
+            P.X_ct[(size_t)b * w + j] = is_obs ? no_t : 0.f;
         }
         if (j < P.inp_b) {
             const size_t w = P.inp_b;
             const float xt = (1.0f - tt) * xx + tt * av;             // fql.py:55
-            P.X_bc[(size_t)b * w + j] = is_obs ? o : (is_act ? xt : (j == od + ad ? tt : 0.f));
-            P.X_eu[(size_t)b * w + j] = is_obs ? o : (is_act ? zz : 0.f);  // t_0 = 0
-            if (P.X_e0) P.X_e0[(size_t)b * w + j] = is_obs ? o : 0.f;
+            P.X_bc[(size_t)b * w + j] = is_obs ? o_bc : (is_act ? xt : (j == od + ad ? tt : 0.f));
+            P.X_eu[(size_t)b * w + j] = is_obs ? o_bc : (is_act ? zz : 0.f);  // t_0 = 0; encoded once (fql.py:162-163)
+            if (P.X_e0) P.X_e0[(size_t)b * w + j] = is_obs ? o_bc : 0.f;
         }
         if (is_act) {
             P.vel[(size_t)b * P.ap + a] = av - xx;                     // fql.py:56
@@ -1692,6 +1707,23 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_euler_persistent_kernel(const
         }
         if (tid == 0) __hip_atomic_store((FQL_GAS unsigned*)(P.epoch + team), ep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// Encoder head backward entry (utils/encoders.py:98, MLP with activate_final): dZ = (dXa[:, :n] (+ dXb[:, :n])) GELU'(z),
+// dXa / dXb = the layer-0 input gradients of the module's MLP(s) ([M, ld], encoding in the first n columns)
+struct EncDzArgs {
+    const float *dxa, *dxb;  // dxb may be null
+    const float* z;          // [M, n] pre-activation of the encoder's Dense
+    float* dz;               // [M, n]
+    int M, n, ld;
+};
+__global__ __launch_bounds__(FQL_THREADS) void fql_enc_dz_kernel(const EncDzArgs P) {
+    const int e = blockIdx.x * FQL_THREADS + threadIdx.x;
+    if (e >= P.M * P.n) return;
+    const int r = e / P.n, j = e - r * P.n;
+    float g = ldg(P.dxa + (size_t)r * P.ld + j);
+    if (P.dxb) g += ldg(P.dxb + (size_t)r * P.ld + j);
+    stg(P.dz + e, g * gelu_grad_f(ldg(P.z + e)));
 }
 
 // sample_actions / flow_actions input assembly: X[n_pad, inp] = concat(obs, noise[, t=0])

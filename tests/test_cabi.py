@@ -91,8 +91,10 @@ def test_null_handles_are_rejected(lib):
 def test_mirror_rejects_bad_config_before_touching_the_device():
     import fql_amd
     ob, ac = np.zeros((1, 5), np.float32), np.zeros((1, 2), np.float32)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):                     # an encoder needs image observations [H, W, C]
         fql_amd.FQLAgent.create(0, ob, ac, dict(encoder='impala_small'))
+    with pytest.raises(NotImplementedError):            # only impala_small (BASELINE config 5) is built
+        fql_amd.FQLAgent.create(0, np.zeros((1, 64, 64, 9), np.uint8), ac, dict(encoder='impala_large'))
     with pytest.raises(ValueError):
         fql_amd.FQLAgent.create(0, np.zeros((1, 8, 8, 3), np.float32), ac, {})
     with pytest.raises(ValueError):
