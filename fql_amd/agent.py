@@ -234,16 +234,20 @@ class FQLAgent:
         return self._eval(observations, noises, None, flow=True)
 
     def _eval(self, observations, noises, seed, flow):
-        od, ad = self.config['ob_dims'][0], self.config['action_dim']
+        obd, ad = tuple(self.config['ob_dims']), self.config['action_dim']
+        vis = len(obd) == 3
+        od = obd[0] if not vis else None
         is_torch = hasattr(observations, 'data_ptr')
-        lead = tuple(observations.shape[:-1])
+        if vis and tuple(observations.shape[-3:]) != obd:
+            raise ValueError(f'observations must end in {obd}, got {tuple(observations.shape)}')
+        lead = tuple(observations.shape[:-3]) if vis else tuple(observations.shape[:-1])
         if not flow and noises is None and seed is not None and np.ndim(seed) == 1 and np.size(seed) == 2:
             # a JAX key (what main.py:225 / utils/evaluation.py:98-101 pass): draw exactly the noise the reference draws
             noises = jax_prng.sample_actions_noise(np.asarray(seed), lead, ad)
-        if int(observations.shape[-1]) != od:
+        if not vis and int(observations.shape[-1]) != od:
             raise ValueError(f'observations last dim must be {od}, got {tuple(observations.shape)}')
         n = int(np.prod(lead)) if lead else 1
-        o = _Arg(observations, (n, od))
+        o = _Arg(observations, (n,) + obd, u8=vis)
         z = _Arg(noises, (n, ad))
         if is_torch and observations.is_cuda:
             torch = _torch()
@@ -265,7 +269,21 @@ class FQLAgent:
         return out
 
     # -- device-resident dataset (utils/datasets.py Dataset/ReplayBuffer on the GPU) -------------
-    def upload_dataset(self, dataset, capacity: Optional[int] = None):
+    def upload_dataset(self, dataset, capacity: Optional[int] = None, frame_stack: Optional[int] = None, p_aug: Optional[float] = None):
+        """Dataset.create(...) arrays -> HBM.  Visual agents: `observations` / `next_observations` are the uint8 FRAMES
+        [N, H, W, C / frame_stack] and `terminals` marks episode ends; frame stacking (main.py:120-121 sets
+        dataset.frame_stack) and the random crop (dataset.p_aug) then happen in the device-side gather."""
+        if len(self.config['ob_dims']) == 3:
+            fs = int(frame_stack if frame_stack is not None else (self.config.get('frame_stack') or 1))
+            pa = float(p_aug if p_aug is not None else (self.config.get('p_aug') or 0.0))
+            n = int(len(dataset['observations']))
+            H, W, Cc = self.config['ob_dims']
+            fshape = (n, H, W, Cc // fs)
+            fr = _Arg(dataset['observations'], fshape, u8=True)
+            nf = _Arg(dataset['next_observations'], fshape, u8=True)
+            rest = [_Arg(dataset[k]) for k in ('actions', 'rewards', 'masks', 'terminals')]
+            self._check(self._lib.fql_dataset_upload_frames(self._h, n, fr.ptr, nf.ptr, *[a.ptr for a in rest], fs, pa))
+            return
         n = int(len(dataset['observations']))
         cap = int(capacity) if capacity is not None else max(n, 1)
         args = [_Arg(dataset[k]) for k in BATCH_KEYS]
@@ -281,8 +299,10 @@ class FQLAgent:
         self._check(self._lib.fql_dataset_size(self._h, C.byref(s), C.byref(p)))
         return int(s.value), int(p.value)
 
-    def update_from_dataset(self, batch_size=None, idxs=None, noise=None, shard=(0, 0), want_info=False, stream=None):
-        """train_dataset.sample(B) + agent.update(batch) (main.py:201,216) without leaving the device."""
+    def update_from_dataset(self, batch_size=None, idxs=None, noise=None, shard=(0, 0), want_info=False, stream=None,
+                            crop_froms=None):
+        """train_dataset.sample(B) + agent.update(batch) (main.py:201,216) without leaving the device.  Visual agents:
+        `crop_froms` int [B, 2] fixes the random-crop offsets Dataset.augment would draw (None: engine RNG with p_aug)."""
         B = int(batch_size or self.config['batch_size'])
         self._ensure_batch(B)
         nz, nargs = self._noise_args(noise, B)
@@ -294,8 +314,16 @@ class FQLAgent:
                 keep = np.ascontiguousarray(idxs, dtype=np.int64); ip = keep.ctypes.data
             if (keep.numel() if hasattr(keep, 'numel') else keep.size) != B:
                 raise ValueError('idxs must have batch_size entries')
-        self._check(self._lib.fql_update_from_dataset(self._h, ip, B, int(shard[0]), int(shard[1]),
-                                                      C.byref(nz) if nz else None, None, stream))
+        if crop_froms is not None:
+            ck = np.ascontiguousarray(crop_froms, dtype=np.int32)
+            if ck.shape != (B, 2):
+                raise ValueError('crop_froms must be [batch_size, 2]')
+            self._check(self._lib.fql_update_from_frames(self._h, ip, ck.ctypes.data, B, int(shard[0]), int(shard[1]),
+                                                         C.byref(nz) if nz else None, None, stream))
+            keep = (keep, ck)
+        else:
+            self._check(self._lib.fql_update_from_dataset(self._h, ip, B, int(shard[0]), int(shard[1]),
+                                                          C.byref(nz) if nz else None, None, stream))
         self._keep = (keep, nargs)
         return self, (self.read_info() if want_info else None)
 

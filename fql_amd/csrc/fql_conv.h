@@ -43,9 +43,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
     float* in_s = lds;                                 // [(R+2)][(W+2)][CS]
     float* w_s = lds + (R + 2) * PW * CS;              // [Co][WS]
     const int blocks_per_img = H / R;
-    const int n = blockIdx.x / blocks_per_img, y0 = (blockIdx.x % blocks_per_img) * R;
+    const int nblocks = P.N * blocks_per_img;
 
-    // ---- weights -> LDS, transposed to [out channel][k]
+    // ---- weights -> LDS, transposed to [out channel][k]; staged once, the workgroup then walks its share of the row blocks
     {
         const int total = 9 * Ci * Co;
         for (int e = tid; e < total; e += FQL_THREADS) {
@@ -56,6 +56,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
             w_s[o * WS + k] = v;
         }
     }
+    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const int n = blk / blocks_per_img, y0 = (blk % blocks_per_img) * R;
+    __syncthreads();  // the previous block's fragments are consumed (first pass: orders nothing that matters)
     // ---- input rows y0-1 .. y0+R with zero halo
     if (P.in_mode == 2) {
         const unsigned char* src = (const unsigned char*)P.in + (size_t)n * H * W * P.Ci_real;
@@ -133,6 +136,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
             }
         }
     }
+    }  // row blocks
 }
 
 __global__ __launch_bounds__(FQL_THREADS) void fql_conv3x3_kernel(const ConvArgs P) {
@@ -144,18 +148,20 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_conv3x3_kernel(const ConvArgs
 // ------------------------------------------------------------------------------------------------
 // conv3x3 weight gradient: dK[t][c][o] = sum_{n,y,x} f(in[n,y+ty-1,x+tx-1,c]) dOut[n,y,x,o], db[o] = sum dOut.
 // Contraction over N H W pixels: every workgroup walks its share of the (image, row block) list with the input rows and
-// the dOut rows in LDS; each WAVE owns a quarter of the block's 16-pixel groups and keeps all 9 (Ci/16)(Co/16) output
-// tiles in registers; per-wave partials go to memory and fql_conv_wgrad_reduce_kernel folds them in fixed order.
+// the dOut rows in LDS.  The 9 (Ci/16) (tap, input-channel tile) units are dealt round-robin to the 4 waves; a wave keeps
+// its units' 16 x Co accumulators in registers over ALL pixels the workgroup sees (no cross-wave reduction), so one
+// partial [9 Ci + 1][Co] per workgroup goes to memory and fql_conv_wgrad_reduce_kernel folds them in fixed order.
 // ------------------------------------------------------------------------------------------------
 struct ConvWgradArgs {
     const void* in;      // forward input of the convolution ([N,H,W,Ci_real] float or uint8)
     const float* dout;   // [N,H,W,Co]
-    float* partial;      // [nparts][9 Ci + 1][Co]   (last row: bias partial)
+    float* partial;      // [gridDim.x][9 Ci + 1][Co]   (last row: bias partial)
     int N, H, W, Ci, Ci_real, Co, in_mode, R, nblocks;
 };
 
 template <int CI_TILES, int CO_TILES>
 __device__ __forceinline__ void conv_wgrad_body(const ConvWgradArgs& P, float* lds) {
+    constexpr int NUNITS = 9 * CI_TILES, NU = (NUNITS + 3) / 4;  // units per wave (round-robin: unit = wave + 4 k)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 15, q = lane >> 4;
     const int H = P.H, W = P.W, Ci = P.Ci, Co = P.Co, R = P.R;
@@ -164,16 +170,20 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradArgs& P, float* l
     float* d_s = lds + (R + 2) * PW * CS;    // [R W][DS]
     const int blocks_per_img = H / R;
     const int ntiles = R * W / 16;
-    f32x4 acc[9][CI_TILES][CO_TILES];
+    f32x4 acc[NU][CO_TILES];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int k = 0; k < NU; ++k)
 #pragma unroll
-        for (int i = 0; i < CI_TILES; ++i)
-#pragma unroll
-            for (int j = 0; j < CO_TILES; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < CO_TILES; ++j) acc[k][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bs[CO_TILES];
 #pragma unroll
     for (int j = 0; j < CO_TILES; ++j) bs[j] = 0.f;
+    int uoff[NU];  // LDS offset of unit k's tap and channel tile (CS-strided pixel layout)
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+        const int u = min(wave + 4 * k, NUNITS - 1), t = u / CI_TILES, i = u - t * CI_TILES;
+        uoff[k] = ((t / 3) * PW + (t % 3)) * CS + 16 * i + c;
+    }
 
     for (int blk = blockIdx.x; blk < P.nblocks; blk += gridDim.x) {
         const int n = blk / blocks_per_img, y0 = (blk % blocks_per_img) * R;
@@ -209,54 +219,57 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradArgs& P, float* l
             }
         }
         __syncthreads();
-        for (int pg = wave; pg < ntiles; pg += 4) {
-            // B fragments: dOut[pixel 16 pg + 4 q + s][16 j + c]
+        for (int pg = 0; pg < ntiles; ++pg) {
+            // B fragments: dOut[pixel 16 pg + 4 q + s][16 j + c]   (every wave reads them: they are shared by all units)
             float b[CO_TILES][4];
 #pragma unroll
             for (int j = 0; j < CO_TILES; ++j)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    b[j][s] = d_s[(16 * pg + 4 * q + s) * DS + 16 * j + c];
-                    bs[j] += b[j][s];
-                }
+                for (int s = 0; s < 4; ++s) b[j][s] = d_s[(16 * pg + 4 * q + s) * DS + 16 * j + c];
+            if (wave == 0) {
+#pragma unroll
+                for (int j = 0; j < CO_TILES; ++j) bs[j] += (b[j][0] + b[j][1]) + (b[j][2] + b[j][3]);
+            }
             int pb[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int p = 16 * pg + 4 * q + s;
-                pb[s] = ((p / W) * PW + (p % W)) * CS + c;
+                pb[s] = ((p / W) * PW + (p % W)) * CS;
             }
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int toff = ((t / 3) * PW + (t % 3)) * CS;
-#pragma unroll
-                for (int i = 0; i < CI_TILES; ++i) {
+            for (int k = 0; k < NU; ++k) {
+                if (wave + 4 * k < NUNITS) {   // wave-uniform
                     float a[4];  // A[row = in channel 16 i + c][k = pixel]
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) a[s] = in_s[pb[s] + toff + 16 * i];
+                    for (int s = 0; s < 4; ++s) a[s] = in_s[pb[s] + uoff[k]];
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
 #pragma unroll
-                        for (int j = 0; j < CO_TILES; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[j][s], acc[t][i][j], 0, 0, 0);
+                        for (int j = 0; j < CO_TILES; ++j) acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[j][s], acc[k][j], 0, 0, 0);
                 }
             }
         }
     }
-    // ---- per-wave partial: rows k = t Ci + 16 i + 4 q + r, cols 16 j + c
-    float* out = P.partial + ((size_t)blockIdx.x * 4 + wave) * (size_t)(9 * Ci + 1) * Co;
+    // ---- per-workgroup partial: rows k = t Ci + 16 i + 4 q + r, cols 16 j + c
+    float* out = P.partial + (size_t)blockIdx.x * (size_t)(9 * Ci + 1) * Co;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int k = 0; k < NU; ++k) {
+        const int u = wave + 4 * k;
+        if (u >= NUNITS) continue;
+        const int t = u / CI_TILES, i = u - t * CI_TILES;
 #pragma unroll
-        for (int i = 0; i < CI_TILES; ++i)
+        for (int j = 0; j < CO_TILES; ++j)
 #pragma unroll
-            for (int j = 0; j < CO_TILES; ++j)
+            for (int r = 0; r < 4; ++r) stg(out + (size_t)(t * Ci + 16 * i + 4 * q + r) * Co + 16 * j + c, acc[k][j][r]);
+    }
+    if (wave == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) stg(out + (size_t)(t * Ci + 16 * i + 4 * q + r) * Co + 16 * j + c, acc[t][i][j][r]);
-#pragma unroll
-    for (int j = 0; j < CO_TILES; ++j) {
-        float v = bs[j];
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (q == 0) stg(out + (size_t)(9 * Ci) * Co + 16 * j + c, v);
+        for (int j = 0; j < CO_TILES; ++j) {
+            float v = bs[j];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (q == 0) stg(out + (size_t)(9 * Ci) * Co + 16 * j + c, v);
+        }
     }
 }
 
@@ -268,7 +281,8 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_conv_wgrad_kernel(const ConvW
     else conv_wgrad_body<1, 1>(P, lds);
 }
 
-// dK (arena layout [9][Cw_rows][Co]) and db from the per-wave partials, summed in index order (deterministic)
+// dK (arena layout [9][Cw_rows][Co]) and db from the per-workgroup partials.  One workgroup = 64 consecutive elements; its
+// 4 waves take every 4th partial each (coalesced 256-byte rows), meet in LDS and are added in wave order: deterministic.
 struct ConvWredArgs {
     const float* partial;
     float* dK;
@@ -276,21 +290,25 @@ struct ConvWredArgs {
     int nparts, Ci, Co, Cw_rows;
 };
 __global__ __launch_bounds__(FQL_THREADS) void fql_conv_wgrad_reduce_kernel(const ConvWredArgs P) {
-    const int e = blockIdx.x * FQL_THREADS + threadIdx.x;
-    const int rows = 9 * P.Ci + 1;
-    if (e >= rows * P.Co) return;
-    const int k = e / P.Co, o = e - k * P.Co;
-    const size_t stride = (size_t)rows * P.Co;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int p = 0;
-    for (; p + 4 <= P.nparts; p += 4) {
-        s0 += ldg(P.partial + (size_t)p * stride + e);
-        s1 += ldg(P.partial + (size_t)(p + 1) * stride + e);
-        s2 += ldg(P.partial + (size_t)(p + 2) * stride + e);
-        s3 += ldg(P.partial + (size_t)(p + 3) * stride + e);
+    __shared__ float red[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 64 + lane;
+    const int rows = 9 * P.Ci + 1, total = rows * P.Co;
+    const size_t stride = (size_t)total;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < total) {
+        int p = wave;
+        for (; p + 4 < P.nparts; p += 8) {
+            s0 += ldg(P.partial + (size_t)p * stride + e);
+            s1 += ldg(P.partial + (size_t)(p + 4) * stride + e);
+        }
+        if (p < P.nparts) s0 += ldg(P.partial + (size_t)p * stride + e);
     }
-    for (; p < P.nparts; ++p) s0 += ldg(P.partial + (size_t)p * stride + e);
-    const float s = (s0 + s1) + (s2 + s3);
+    red[wave][lane] = s0 + s1;
+    __syncthreads();
+    if (wave != 0 || e >= total) return;
+    const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    const int k = e / P.Co, o = e - k * P.Co;
     if (k == 9 * P.Ci) { P.db[o] = s; return; }
     const int t = k / P.Ci, ci = k - t * P.Ci;
     if (ci < P.Cw_rows) P.dK[((size_t)t * P.Cw_rows + ci) * P.Co + o] = s;
@@ -403,4 +421,35 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_img_gather_kernel(const ImgGa
     P.obs[e] = P.frames[(size_t)so * img + pix];
     if (f == P.k - 1) P.nobs[e] = P.next_frames[(size_t)t * img + pix];
     else P.nobs[e] = P.frames[(size_t)max(t - (P.k - 2 - f), i0) * img + pix];
+}
+
+// index draw (utils/datasets.py:64-66), episode starts and crop offsets (utils/datasets.py:102-112) of one batch
+struct ImgIndexArgs {
+    const int64_t* idx_in;    // [B] or null = uniform in [lo, lo + span) from the engine RNG (same stream as the state path)
+    const int* crop_in;       // [B][2] or null = engine RNG
+    const int64_t* ds_init;   // [n] first index of each row's episode
+    const DevState* st;
+    uint64_t key;
+    int64_t lo, span;
+    float p_aug;
+    int B, pad;
+    int64_t* idx;             // out [B]
+    int64_t* init;            // out [B]
+    int* crop;                // out [B][2]
+};
+__global__ __launch_bounds__(FQL_THREADS) void fql_img_index_kernel(const ImgIndexArgs P) {
+    const int b = blockIdx.x * FQL_THREADS + threadIdx.x;
+    if (b >= P.B) return;
+    const uint64_t step = P.st->rng_step;
+    int64_t i = P.idx_in ? P.idx_in[b] : P.lo + (int64_t)(((uint64_t)rng_u32(P.key, step, 7u, (uint32_t)b) * (uint64_t)P.span) >> 32);
+    P.idx[b] = i;
+    P.init[b] = P.ds_init[i];
+    int cy = P.pad, cx = P.pad;   // crop_from == padding: the identity slice
+    if (P.crop_in) { cy = P.crop_in[2 * b]; cx = P.crop_in[2 * b + 1]; }
+    else if (P.p_aug > 0.f && rng_uniform(P.key, step, 8u, 0u) < P.p_aug) {   // ONE coin per batch (utils/datasets.py:90-92)
+        const uint32_t w = 2u * (uint32_t)P.pad + 1u;
+        cy = (int)(((uint64_t)rng_u32(P.key, step, 9u, (uint32_t)b) * w) >> 32);
+        cx = (int)(((uint64_t)rng_u32(P.key, step, 10u, (uint32_t)b) * w) >> 32);
+    }
+    P.crop[2 * b] = cy; P.crop[2 * b + 1] = cx;
 }

@@ -258,6 +258,13 @@ struct fql_engine {
     float *ds_obs = nullptr, *ds_act = nullptr, *ds_rew = nullptr, *ds_mask = nullptr, *ds_nobs = nullptr;
     float* ds_row = nullptr;
     int64_t ds_size = 0, ds_cap = 0, ds_ptr = 0;
+    // frames dataset (visual agents): uint8 frames + per-row episode start, frame stacking and crop done by the gather
+    unsigned char *ds_frames = nullptr, *ds_next_frames = nullptr;
+    int64_t* ds_init = nullptr;
+    int ds_fs = 0;
+    float ds_paug = 0.f;
+    int64_t* in_init = nullptr;   // [B] workspace
+    int *in_crop = nullptr, *in_crop_user = nullptr;  // [B][2]
 
     // eval (sample_actions / flow_actions) workspaces keyed by padded row count
     struct Eval {
@@ -267,6 +274,10 @@ struct fql_engine {
         PassBuf p_os, p_eu;
         Program prog_os, prog_flow;
         float *st_obs = nullptr, *st_noise = nullptr, *st_out = nullptr;
+        // visual agents: the rows are images; they pass through the module's encoder first (agents/fql.py:162-163, networks.py:221)
+        unsigned char* st_img = nullptr;
+        EncBuf eb_os, eb_bc;
+        Program prog_enc_os, prog_enc_bc;
     };
     std::map<int, std::unique_ptr<Eval>> evals;
 
@@ -575,7 +586,7 @@ struct fql_engine {
         if (bwd) {
             b.dz = dalloc(owner, (size_t)n * enc_dim);
             b.dA = dalloc(owner, maxel); b.dB = dalloc(owner, maxel); b.dC = dalloc(owner, maxel);
-            b.wpart = dalloc(owner, (size_t)1024 * (9 * 32 + 1) * 32);
+            b.wpart = dalloc(owner, (size_t)256 * (9 * 32 + 1) * 32);
         }
         return b;
     }
@@ -667,7 +678,7 @@ struct fql_engine {
         push(pr, op);
         Op r{};
         r.type = OP_CONV_WRED;
-        r.cwr = ConvWredArgs{b.wpart, G + c.w, G + c.b, op.cw_grid * 4, a.Ci, a.Co, c.cin};
+        r.cwr = ConvWredArgs{b.wpart, G + c.w, G + c.b, op.cw_grid, a.Ci, a.Co, c.cin};
         r.reads = {b.wpart};
         r.writes = {G + c.w, G + c.b};
         push(pr, r);
@@ -1381,7 +1392,7 @@ struct fql_engine {
                 case OP_CONV: {
                     const ConvArgs& a = L.op.conv;
                     const size_t lds = ((size_t)(a.R + 2) * (a.W + 2) * (a.Ci + 4) + (size_t)a.Co * (9 * a.Ci + 4)) * sizeof(float);
-                    hipLaunchKernelGGL(fql_conv3x3_kernel, dim3(a.N * (a.H / a.R)), dim3(FQL_THREADS), lds, s, a);
+                    hipLaunchKernelGGL(fql_conv3x3_kernel, dim3(std::min(a.N * (a.H / a.R), 2 * num_cus)), dim3(FQL_THREADS), lds, s, a);
                     break;
                 }
                 case OP_POOL: {
@@ -1405,7 +1416,7 @@ struct fql_engine {
                 case OP_CONV_WRED: {
                     const ConvWredArgs& a = L.op.cwr;
                     const int tot = (9 * a.Ci + 1) * a.Co;
-                    hipLaunchKernelGGL(fql_conv_wgrad_reduce_kernel, dim3((tot + FQL_THREADS - 1) / FQL_THREADS), dim3(FQL_THREADS), 0, s, a);
+                    hipLaunchKernelGGL(fql_conv_wgrad_reduce_kernel, dim3((tot + 63) / 64), dim3(FQL_THREADS), 0, s, a);
                     break;
                 }
                 case OP_ENC_DZ: {
@@ -1760,7 +1771,7 @@ struct fql_engine {
         in_obs = dalloc(W, (size_t)B * od); in_nobs = dalloc(W, (size_t)B * od);
         in_act = dalloc(W, (size_t)B * ad); in_rew = dalloc(W, B); in_mask = dalloc(W, B);
         for (int i = 0; i < 5; ++i) in_noise[i] = dalloc(W, (size_t)B * ad);
-        in_idx = (int64_t*)dalloc(W, (size_t)B * 2);
+        in_idx = (int64_t*)dalloc(W, (size_t)B * 4);   // [2][B]: indices in use, staging of host indices (frames path)
         X_os = dalloc(W, (size_t)3 * B * inp_c); X_bc = dalloc(W, (size_t)B * inp_b); X_eu = dalloc(W, (size_t)B * inp_b);
         X_c1 = dalloc(W, (size_t)B * inp_c); X_c2 = dalloc(W, (size_t)B * inp_c); X_ct = dalloc(W, (size_t)B * inp_c);
         const int ap = pad16(ad);
@@ -1798,6 +1809,8 @@ struct fql_engine {
         if (visual) {
             const size_t ib = (size_t)cfg.img_h * cfg.img_w * cfg.img_c;
             img_all = (unsigned char*)dalloc(W, (2 * (size_t)B * ib + 3) / 4 + 4);
+            in_init = (int64_t*)dalloc(W, (size_t)B * 2);
+            in_crop = (int*)dalloc(W, (size_t)B * 2); in_crop_user = (int*)dalloc(W, (size_t)B * 2);
             eb_os = make_enc_buf(W, ENC_OS, 2 * B, img_all, true);
             eb_c = make_enc_buf(W, ENC_C, B, img_all, true);
             eb_t = make_enc_buf(W, ENC_T, B, img_all + (size_t)B * ib, false);
@@ -1930,6 +1943,46 @@ struct fql_engine {
         drain_staging(s);
         set_source(d, s);
     }
+    // Dataset.sample for image datasets (utils/datasets.py:68-92): indices, frame stacking, random crop -> img_all, on the device
+    void source_from_frames(const int64_t* idx, const int32_t* crop, int batch, int64_t lo, int64_t hi, const fql_noise* nz, hipStream_t s) {
+        if (batch != B) invalid("batch_size %d does not match the engine's workspace (%d)", batch, B);
+        if (!visual || !ds_frames || ds_size <= 0) throw Invalid{"no frames dataset uploaded (fql_dataset_upload_frames)"};
+        if (lo == 0 && hi == 0) hi = ds_size;
+        if (lo < 0 || hi > ds_size || lo >= hi) invalid("bad sampling range [%lld, %lld) for dataset of %lld rows", (long long)lo, (long long)hi, (long long)ds_size);
+        const int64_t* idx_dev = nullptr;
+        if (idx) {
+            if (is_device_ptr(idx)) idx_dev = idx;
+            else {
+                HIP_CHECK(hipMemcpyAsync(in_idx + B, idx, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, s));   // second half of in_idx
+                staged_host = true;
+                idx_dev = in_idx + B;
+            }
+        }
+        const int* crop_dev = nullptr;
+        if (crop) {
+            if (is_device_ptr(crop)) crop_dev = crop;
+            else {
+                HIP_CHECK(hipMemcpyAsync(in_crop_user, crop, (size_t)B * 2 * sizeof(int), hipMemcpyHostToDevice, s));
+                staged_host = true;
+                crop_dev = in_crop_user;
+            }
+        }
+        ImgIndexArgs ia{idx_dev, crop_dev, ds_init, d_state, seed, lo, hi - lo, ds_paug, B, 3, in_idx, in_init, in_crop};
+        hipLaunchKernelGGL(fql_img_index_kernel, dim3((B + FQL_THREADS - 1) / FQL_THREADS), dim3(FQL_THREADS), 0, s, ia);
+        const size_t ib = (size_t)cfg.img_h * cfg.img_w * cfg.img_c;
+        ImgGatherArgs ga{ds_frames, ds_next_frames, in_idx, in_init, in_crop, img_all, img_all + (size_t)B * ib,
+                         B, cfg.img_h, cfg.img_w, cfg.img_c / ds_fs, ds_fs, 3};
+        const size_t tot = (size_t)B * ib;
+        hipLaunchKernelGGL(fql_img_gather_kernel, dim3((unsigned)((tot + FQL_THREADS - 1) / FQL_THREADS)), dim3(FQL_THREADS), 0, s, ga);
+        HIP_CHECK(hipGetLastError());
+        SrcDesc d{};
+        d.act = ds_act; d.rew = ds_rew; d.mask = ds_mask;
+        d.idx = in_idx;
+        fill_noise(d, nz, s);
+        d.advance = 1;
+        drain_staging(s);
+        set_source(d, s);
+    }
     void finish_info(float* info, int n, hipStream_t s) {
         if (!info) return;
         if (is_device_ptr(info)) {
@@ -1966,6 +2019,18 @@ struct fql_engine {
                          1.0f / (float)fs, (float)(s + 1) / (float)fs);
         schedule(ev->prog_os, W);
         schedule(ev->prog_flow, W);
+        if (visual) {
+            const size_t ib = (size_t)cfg.img_h * cfg.img_w * cfg.img_c;
+            ev->st_img = (unsigned char*)dalloc(W, ((size_t)n_pad * ib + 3) / 4 + 4);
+            ev->eb_os = make_enc_buf(W, ENC_OS, n_pad, ev->st_img, false);
+            ev->eb_bc = make_enc_buf(W, ENC_BC, n_pad, ev->st_img, false);
+            emit_lane = 1;   // throughput kernels (the encoder's Dense has K = flat > 1024)
+            emit_encoder_forward(ev->prog_enc_os, ev->eb_os);
+            emit_encoder_forward(ev->prog_enc_bc, ev->eb_bc);
+            emit_lane = 0;
+            schedule(ev->prog_enc_os, W);
+            schedule(ev->prog_enc_bc, W);
+        }
         Eval& ref = *ev;
         evals[n_pad] = std::move(ev);
         return ref;
@@ -1975,11 +2040,21 @@ struct fql_engine {
         if (!obs || !out) invalid("observations/out must not be NULL");
         if (flow && !noise) invalid("noises must not be NULL");
         const int od = cfg.obs_dim, ad = cfg.act_dim;
-        const int chunk_cap = 4096;
+        const int chunk_cap = visual ? 256 : 4096;
         for (int start = 0; start < n; start += chunk_cap) {
             const int m = std::min(chunk_cap, n - start);
-            Eval& ev = get_eval(pad16(m));
-            const float* o = stage(obs + (size_t)start * od, ev.st_obs, (size_t)m * od, s);
+            Eval& ev = get_eval(visual ? (m + 63) & ~63 : pad16(m));
+            const float* o;
+            if (visual) {   // `obs` is uint8 [n, H, W, C]: encode with the module's encoder, then proceed on the encodings
+                const size_t ib = (size_t)cfg.img_h * cfg.img_w * cfg.img_c;
+                const unsigned char* src = reinterpret_cast<const unsigned char*>(obs) + (size_t)start * ib;
+                HIP_CHECK(hipMemcpyAsync(ev.st_img, src, (size_t)m * ib, hipMemcpyDefault, s));
+                if (!is_device_ptr(src)) staged_host = true;
+                run_launches(flow ? ev.prog_enc_bc : ev.prog_enc_os, s);
+                o = flow ? ev.eb_bc.E : ev.eb_os.E;
+            } else {
+                o = stage(obs + (size_t)start * od, ev.st_obs, (size_t)m * od, s);
+            }
             const float* z = noise ? stage(noise + (size_t)start * ad, ev.st_noise, (size_t)m * ad, s) : nullptr;
             drain_staging(s);
             AssembleArgs a{o, z, flow ? ev.Xf : ev.X, seed, sd + (uint64_t)start, m, ev.n_pad, od, ad,
@@ -2128,6 +2203,7 @@ int fql_destroy(fql_handle h) {
     hipFree(h->P); hipFree(h->G); hipFree(h->Mu); hipFree(h->Nu); hipFree(h->d_chunks); hipFree(h->d_partials); hipFree(h->d_leaf_range); hipFree(h->d_state); hipFree(h->d_src);
     if (h->h_src_ring) hipHostFree(h->h_src_ring);
     hipFree(h->ds_obs); hipFree(h->ds_act); hipFree(h->ds_rew); hipFree(h->ds_mask); hipFree(h->ds_nobs); hipFree(h->ds_row);
+    hipFree(h->ds_frames); hipFree(h->ds_next_frames); hipFree(h->ds_init);
     if (h->stream) hipStreamDestroy(h->stream);
     if (h->stream2) hipStreamDestroy(h->stream2);
     if (h->stream3) hipStreamDestroy(h->stream3);
@@ -2381,6 +2457,7 @@ int fql_grad_buckets(fql_handle h, size_t offsets[2], size_t lengths[2]) {
 }
 int fql_update_from_dataset(fql_handle h, const int64_t* idx, int batch_size, int64_t lo, int64_t hi, const fql_noise* noise,
                             float* info13, void* stream) {
+    if (h && h->visual) return fql_update_from_frames(h, idx, nullptr, batch_size, lo, hi, noise, info13, stream);
     if (h && h->prog_full.exec && !h->began) {
         FQL_TRY(h, {
             hipStream_t s = pick(h, stream);
@@ -2444,4 +2521,58 @@ extern "C" int fql_debug_enc(fql_handle h, int enc, int code, void* out, size_t 
     if (!src) return FQL_E_NOTFOUND;
     hipDeviceSynchronize();
     return hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? FQL_OK : FQL_E_HIP;
+}
+
+int fql_dataset_upload_frames(fql_handle h, int64_t n, const uint8_t* frames, const uint8_t* next_frames, const float* act,
+                              const float* rew, const float* mask, const float* terminals, int frame_stack, float p_aug) {
+    if (!h) return FQL_E_INVALID;
+    FQL_TRY(h, {
+        if (!h->visual) throw Invalid{"fql_dataset_upload_frames needs an agent created with an encoder"};
+        if (n <= 0 || !frames || !next_frames || !act || !rew || !mask || !terminals) invalid("frames dataset pointers must not be NULL (n=%lld)", (long long)n);
+        if (frame_stack < 1 || h->cfg.img_c % frame_stack) invalid("frame_stack %d must divide the %d image channels", frame_stack, h->cfg.img_c);
+        if (p_aug < 0.f || p_aug > 1.f) invalid("p_aug must be in [0, 1]");
+        HIP_CHECK(hipDeviceSynchronize());
+        hipFree(h->ds_frames); hipFree(h->ds_next_frames); hipFree(h->ds_init);
+        hipFree(h->ds_act); hipFree(h->ds_rew); hipFree(h->ds_mask);
+        h->ds_frames = h->ds_next_frames = nullptr; h->ds_init = nullptr; h->ds_act = h->ds_rew = h->ds_mask = nullptr;
+        const size_t fb = (size_t)h->cfg.img_h * h->cfg.img_w * (h->cfg.img_c / frame_stack);
+        HIP_CHECK(hipMalloc((void**)&h->ds_frames, (size_t)n * fb));
+        HIP_CHECK(hipMalloc((void**)&h->ds_next_frames, (size_t)n * fb));
+        HIP_CHECK(hipMemcpy(h->ds_frames, frames, (size_t)n * fb, hipMemcpyDefault));
+        HIP_CHECK(hipMemcpy(h->ds_next_frames, next_frames, (size_t)n * fb, hipMemcpyDefault));
+        auto up = [&](float*& dst, const float* src, size_t w) {
+            HIP_CHECK(hipMalloc((void**)&dst, (size_t)n * w * sizeof(float)));
+            HIP_CHECK(hipMemcpy(dst, src, (size_t)n * w * sizeof(float), hipMemcpyDefault));
+        };
+        up(h->ds_act, act, h->cfg.act_dim); up(h->ds_rew, rew, 1); up(h->ds_mask, mask, 1);
+        // utils/datasets.py:58-62: terminal_locs = nonzero(terminals > 0); initial_locs = [0, terminal_locs[:-1] + 1];
+        // a row's episode start = the last initial_loc <= row (searchsorted(..., side='right') - 1, utils/datasets.py:75)
+        std::vector<float> term((size_t)n);
+        HIP_CHECK(hipMemcpy(term.data(), terminals, (size_t)n * sizeof(float), hipMemcpyDefault));
+        std::vector<int64_t> tl;
+        for (int64_t i = 0; i < n; ++i) if (term[i] > 0.f) tl.push_back(i);
+        std::vector<int64_t> init((size_t)n);
+        int64_t cur = 0;
+        size_t k = 0;   // next terminal whose successor may start an episode; the LAST terminal never starts one (terminal_locs[:-1])
+        for (int64_t i = 0; i < n; ++i) {
+            while (k + 1 < tl.size() && tl[k] + 1 <= i) { cur = tl[k] + 1; ++k; }
+            init[i] = cur;
+        }
+        HIP_CHECK(hipMalloc((void**)&h->ds_init, (size_t)n * sizeof(int64_t)));
+        HIP_CHECK(hipMemcpy(h->ds_init, init.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice));
+        h->ds_fs = frame_stack; h->ds_paug = p_aug;
+        h->ds_size = n; h->ds_cap = n; h->ds_ptr = 0;
+        h->src_valid = false;
+    });
+}
+int fql_update_from_frames(fql_handle h, const int64_t* idx, const int32_t* crop_froms, int batch_size, int64_t lo, int64_t hi,
+                           const fql_noise* noise, float* info13, void* stream) {
+    if (!h) return FQL_E_INVALID;
+    FQL_TRY(h, {
+        hipStream_t s = pick(h, stream);
+        h->source_from_frames(idx, crop_froms, batch_size, lo, hi, noise, s);
+        if (h->prog_full.exec) run_program(h, h->prog_full, s);
+        else { run_program(h, h->prog_fwdbwd, s); run_program(h, h->prog_opt, s); }
+        h->finish_info(info13, FQL_NUM_INFO, s);
+    });
 }

@@ -182,6 +182,19 @@ int fql_update_from_dataset(fql_handle h, const int64_t* idx, int batch_size, in
 int fql_update_from_dataset_begin(fql_handle h, const int64_t* idx, int batch_size, int64_t lo, int64_t hi,
                                   const fql_noise* noise, void* stream);
 
+/* Visual datasets (encoder != 0; utils/datasets.py:73-112): the uint8 frames [n, img_h, img_w, img_c / frame_stack] live in HBM;
+ * a batch row is built on the device as Dataset.sample does: `frame_stack` frames ending at the sampled index, clamped to the first
+ * index of its episode (initial_locs from `terminals`, utils/datasets.py:58-62), concatenated on the channel axis; next_observations
+ * shifts by one and ends with next_frames[idx]; with probability p_aug per BATCH both are edge-padded by 3 and cropped at a
+ * per-sample offset in [0, 6]^2 (Dataset.augment).  Device or host pointers. */
+int fql_dataset_upload_frames(fql_handle h, int64_t n, const uint8_t* frames, const uint8_t* next_frames,
+                              const float* actions, const float* rewards, const float* masks,
+                              const float* terminals, int frame_stack, float p_aug);
+/* fql_update_from_dataset for frames.  crop_froms: int32 [B, 2] (y, x) offsets as Dataset.augment draws them (3, 3 = identity),
+ * or NULL = the engine's RNG (coin with p_aug, then offsets).  fql_update_from_dataset on a frames dataset == this with NULL. */
+int fql_update_from_frames(fql_handle h, const int64_t* idx, const int32_t* crop_froms, int batch_size, int64_t lo,
+                           int64_t hi, const fql_noise* noise, float* info13, void* stream);
+
 /* Blocking read of the info of the last update (the reference reads lazily at log time, main.py:276). */
 int fql_read_info(fql_handle h, float* info13_host);
 

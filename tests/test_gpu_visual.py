@@ -101,3 +101,55 @@ def test_visual_total_loss_matches_oracle_and_changes_nothing():
     after = leaf_dict(agent.get_params())
     for k, v in leaf_dict(params).items():
         np.testing.assert_array_equal(after[k], v)
+
+
+def test_visual_sample_and_flow_actions_match_oracle():
+    """agents/fql.py:135-171 with image observations: encode (once for the flow, fql.py:162-163), then the state-path kernels."""
+    import fql_amd
+    cfg, batch, nz = make_visual(seed=6)
+    agent = fql_amd.FQLAgent.create(2, batch['observations'][:1], batch['actions'][:1], cfg)
+    params = randomize_params(agent.get_params(), seed=7, scale=0.05)
+    agent.set_params(params)
+    ref = O.OracleFQL(params, dict(cfg), (32, 32, 3), 4, np.float64)
+    obs = batch['observations'][:20]
+    z = nz['z'][:20]
+    np.testing.assert_allclose(agent.sample_actions(obs, noises=z), ref.sample_actions(obs, z), atol=5e-6)
+    np.testing.assert_allclose(agent.compute_flow_actions(obs, z), ref.compute_flow_actions(obs, z), atol=2e-5)
+    one = agent.sample_actions(obs[0], noises=z[0])                       # a single image, as the evaluation loop passes
+    np.testing.assert_allclose(one, ref.sample_actions(obs[:1], z[:1])[0], atol=5e-6)
+    assert one.shape == (4,)
+
+
+def test_visual_dataset_gather_stacks_frames_and_crops_like_the_reference():
+    """utils/datasets.py:73-112 on the device: update_from_dataset(idxs, crop_froms) == update(batch built by the oracle)."""
+    import fql_amd
+    from oracle import encoder_oracle as E
+    B, hw, ad, fs = 32, 32, 4, 3
+    cfg, _, _ = make_visual(B=B, hw=hw, c=3 * fs, ad=ad)
+    rng = np.random.default_rng(11)
+    n = 200
+    frames = rng.integers(0, 256, size=(n, hw, hw, 3), dtype=np.uint8)
+    nxt = rng.integers(0, 256, size=(n, hw, hw, 3), dtype=np.uint8)
+    terminals = (rng.random(n) < 0.05).astype(np.float32); terminals[-1] = 1
+    ds = {'observations': frames, 'next_observations': nxt, 'terminals': terminals,
+          'actions': rng.uniform(-1, 1, size=(n, ad)).astype(np.float32),
+          'rewards': -np.ones(n, np.float32), 'masks': 1 - terminals}
+    ex = np.zeros((1, hw, hw, 3 * fs), np.uint8)
+    a = fql_amd.FQLAgent.create(3, ex, ds['actions'][:1], cfg)
+    b = fql_amd.FQLAgent.create(3, ex, ds['actions'][:1], cfg)
+    params = randomize_params(a.get_params(), seed=8, scale=0.05)
+    a.set_params(params); b.set_params(params)
+    a.upload_dataset(ds, frame_stack=fs, p_aug=0.5)
+    idxs = rng.integers(0, n, size=B)
+    idxs[:4] = [0, 1, 2, n - 1]                                            # episode starts: clamped stacking
+    crops = rng.integers(0, 7, size=(B, 2))
+    nz = O.make_noise(B, ad, 12)
+    _, ia = a.update_from_dataset(B, idxs=idxs, noise=nz, want_info=True, crop_froms=crops)
+    obs, nobs = E.stack_frames(frames, nxt, terminals, idxs, fs)
+    batch = {'observations': E.random_crop_batch(obs, crops), 'next_observations': E.random_crop_batch(nobs, crops),
+             'actions': ds['actions'][idxs], 'rewards': ds['rewards'][idxs], 'masks': ds['masks'][idxs]}
+    _, ib = b.update(batch, noise=nz)
+    assert ia == ib                                                          # same kernels on the same bytes: bitwise equal
+    # engine-RNG sampling (indices, coin, offsets) runs and stays finite
+    _, ic = a.update_from_dataset(B, want_info=True)
+    assert all(np.isfinite(v) for v in ic.values())
