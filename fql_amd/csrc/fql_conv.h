@@ -32,9 +32,85 @@ struct ConvArgs {
     int R;                // image rows per workgroup
 };
 
-__device__ __forceinline__ int conv_lds_floats(int R, int W, int Ci, int Co) { return (R + 2) * (W + 2) * (Ci + 4) + Co * (9 * Ci + 4); }
+// Input rows y0-1 .. y0+R of image n (zero halo) -> LDS [(R+2)][(W+2)][Ci+4], in two halves so the global loads of the NEXT
+// row block fly while the matrix cores work on the current one: fetch() issues <= 6 unconditional 16-byte loads per thread
+// into registers (clamped addresses, out-of-image lanes zeroed on commit), commit() writes them to LDS.
+// uint8 images (first convolution): the rows are read as whole dwords (W C / 4 per row) and unpacked on commit; the halo
+// columns and the channel padding are zeroed once per launch and never written again.
+struct ConvTile {
+    static constexpr int NF = 6;
+    const void* in;
+    float* in_s;
+    int H, W, Ci, Ci_real, R, in_mode, CS, PW, tid;
+    f32x4 pre[NF];
+    unsigned prew[NF];
+    int y0;
+    __device__ __forceinline__ void init() {
+        if (in_mode == 2) {
+            const int total = (R + 2) * PW * CS;
+            for (int e = tid; e < total; e += FQL_THREADS) in_s[e] = 0.f;
+        }
+    }
+    __device__ __forceinline__ void fetch(int n, int y0_) {
+        y0 = y0_;
+        if (in_mode == 2) {
+            const int dpr = (W * Ci_real) >> 2, total = (R + 2) * dpr;   // dwords per image row
+            const unsigned* src = (const unsigned*)((const unsigned char*)in + (size_t)n * H * W * Ci_real);
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int e = min(tid + i * FQL_THREADS, total - 1);
+                const int rr = e / dpr, cd = e - rr * dpr;
+                const int yy = min(max(y0 + rr - 1, 0), H - 1);
+                prew[i] = __builtin_nontemporal_load(src + (size_t)yy * dpr + cd);
+            }
+        } else {
+            const int c4 = Ci >> 2, total = (R + 2) * PW * c4;
+            const float* src = (const float*)in + (size_t)n * H * W * Ci;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int e = min(tid + i * FQL_THREADS, total - 1);
+                const int cc = e % c4, px = e / c4;
+                const int xx = min(max(px % PW - 1, 0), W - 1), yy = min(max(y0 + px / PW - 1, 0), H - 1);
+                pre[i] = ldg4(src + ((size_t)yy * W + xx) * Ci + 4 * cc);
+            }
+        }
+    }
+    __device__ __forceinline__ void commit() {
+        if (in_mode == 2) {
+            const int dpr = (W * Ci_real) >> 2, total = (R + 2) * dpr;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int e = tid + i * FQL_THREADS;
+                if (e >= total) continue;
+                const int rr = e / dpr, cd = e - rr * dpr;
+                const int yy = y0 + rr - 1;
+                const bool ok = yy >= 0 && yy < H;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int bi = 4 * cd + k, x = bi / Ci_real, ch = bi - x * Ci_real;
+                    in_s[(rr * PW + x + 1) * CS + ch] = ok ? (float)((prew[i] >> (8 * k)) & 255u) * (1.0f / 255.0f) : 0.f;
+                }
+            }
+        } else {
+            const int c4 = Ci >> 2, total = (R + 2) * PW * c4;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int e = tid + i * FQL_THREADS;
+                if (e >= total) continue;
+                const int cc = e % c4, px = e / c4;
+                const int xx = px % PW - 1, yy = y0 + px / PW - 1;
+                f32x4 v = pre[i];
+                if (in_mode == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                if (xx < 0 || xx >= W || yy < 0 || yy >= H) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(in_s + px * CS + 4 * cc) = v;
+            }
+        }
+    }
+};
 
-template <int CO_TILES>
+// PIPE: next block's input and this block's epilogue operands are fetched ahead of the MFMA loop (first convolution: uint8 rows,
+// little else to hide the latency); the float layers run without it at a quarter of the registers and 2-3x the occupancy.
+template <int CO_TILES, bool PIPE>
 __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 15, q = lane >> 4;
@@ -44,6 +120,12 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
     float* w_s = lds + (R + 2) * PW * CS;              // [Co][WS]
     const int blocks_per_img = H / R;
     const int nblocks = P.N * blocks_per_img;
+    ConvTile T;
+    T.in = P.in; T.in_s = in_s; T.H = H; T.W = W; T.Ci = Ci; T.Ci_real = P.Ci_real; T.R = R; T.in_mode = P.in_mode; T.CS = CS; T.PW = PW; T.tid = tid;
+    if constexpr (PIPE) {
+        T.fetch(blockIdx.x / blocks_per_img, (blockIdx.x % blocks_per_img) * R);
+        T.init();
+    }
 
     // ---- weights -> LDS, transposed to [out channel][k]; staged once, the workgroup then walks its share of the row blocks
     {
@@ -56,41 +138,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
             w_s[o * WS + k] = v;
         }
     }
-    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-    const int n = blk / blocks_per_img, y0 = (blk % blocks_per_img) * R;
-    __syncthreads();  // the previous block's fragments are consumed (first pass: orders nothing that matters)
-    // ---- input rows y0-1 .. y0+R with zero halo
-    if (P.in_mode == 2) {
-        const unsigned char* src = (const unsigned char*)P.in + (size_t)n * H * W * P.Ci_real;
-        const int total = (R + 2) * PW * Ci;
-        for (int e = tid; e < total; e += FQL_THREADS) {
-            const int ci = e % Ci, px = e / Ci, xx = px % PW - 1, yy = y0 + px / PW - 1;
-            float v = 0.f;
-            if (ci < P.Ci_real && xx >= 0 && xx < W && yy >= 0 && yy < H) v = (float)src[((size_t)yy * W + xx) * P.Ci_real + ci] * (1.0f / 255.0f);
-            in_s[px * CS + ci] = v;
-        }
-    } else {
-        const float* src = (const float*)P.in + (size_t)n * H * W * Ci;
-        const int c4 = Ci >> 2, total = (R + 2) * PW * c4;
-        for (int e = tid; e < total; e += FQL_THREADS) {
-            const int cc = e % c4, px = e / c4, xx = px % PW - 1, yy = y0 + px / PW - 1;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
-                v = ldg4(src + ((size_t)yy * W + xx) * Ci + 4 * cc);
-                if (P.in_mode == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-            }
-            *reinterpret_cast<f32x4*>(in_s + px * CS + 4 * cc) = v;
-        }
-    }
-    __syncthreads();
-
-    // ---- MFMA: this wave's row tiles are `wave` and `wave + 4` (16 consecutive pixels of the R x W block each)
     const int ntiles = R * W / 16;
-    f32x4 acc[2][CO_TILES];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < CO_TILES; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     int pbase[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -98,59 +146,114 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
         const int p = 16 * t + c;
         pbase[i] = ((p / W) * PW + (p % W)) * CS + 4 * q;
     }
+    float bv[CO_TILES];
+#pragma unroll
+    for (int j = 0; j < CO_TILES; ++j) bv[j] = P.bias ? ldg(P.bias + 16 * j + c) : 0.f;
     const int ngroups = Ci >> 4;
-    for (int t = 0; t < 9; ++t) {
-        const int toff = ((t / 3) * PW + (t % 3)) * CS;
-        for (int g = 0; g < ngroups; ++g) {
-            f32x4 a[2], b[CO_TILES];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(in_s + pbase[i] + toff + 16 * g);
-#pragma unroll
-            for (int j = 0; j < CO_TILES; ++j) b[j] = *reinterpret_cast<const f32x4*>(w_s + (16 * j + c) * WS + t * Ci + 16 * g + 4 * q);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < CO_TILES; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
-        }
-    }
-    // ---- epilogue.  C layout: col = lane & 15 (channel), row = 4 q + r (pixel of the tile)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int t = wave + 4 * i;
-        if (t >= ntiles) continue;
-#pragma unroll
-        for (int j = 0; j < CO_TILES; ++j) {
-            const int ch = 16 * j + c;
-            const float bv = P.bias ? ldg(P.bias + ch) : 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int p = 16 * t + 4 * q + r;
-                const size_t o = (((size_t)n * H + y0 + p / W) * W + (p % W)) * Co + ch;
-                float v = acc[i][j][r] + bv;
-                if (P.mask) v = (ldg(P.mask + o) > 0.f) ? v : 0.f;
-                if (P.add) v += ldg(P.add + o);
-                stg(P.out + o, v);
-                if (P.out_relu) stg(P.out_relu + o, fmaxf(v, 0.f));
+
+    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const int n = blk / blocks_per_img, y0 = (blk % blocks_per_img) * R;
+        __syncthreads();  // the previous block's fragments are consumed (first pass: the zero fill / weights are in place)
+        if constexpr (PIPE) {
+            T.commit();
+        } else {   // rolled staging loop: few registers, latency hidden by the other resident workgroups
+            const float* src = (const float*)P.in + (size_t)n * H * W * Ci;
+            const int c4 = Ci >> 2, total = (R + 2) * PW * c4;
+            for (int e = tid; e < total; e += FQL_THREADS) {
+                const int cc = e % c4, px = e / c4, xx = px % PW - 1, yy = y0 + px / PW - 1;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
+                    v = ldg4(src + ((size_t)yy * W + xx) * Ci + 4 * cc);
+                    if (P.in_mode == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                }
+                *reinterpret_cast<f32x4*>(in_s + px * CS + 4 * cc) = v;
             }
         }
-    }
+        __syncthreads();
+        const int nxt = blk + gridDim.x;
+        if constexpr (PIPE) { if (nxt < nblocks) T.fetch(nxt / blocks_per_img, (nxt % blocks_per_img) * R); }
+        // epilogue operands of this block: issued now, consumed after the MFMA loop
+        float mk[2][CO_TILES][4], ad[2][CO_TILES][4];
+        if (PIPE)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int t = min(wave + 4 * i, ntiles - 1);
+#pragma unroll
+            for (int j = 0; j < CO_TILES; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int p = 16 * t + 4 * q + r;
+                    const size_t o = (((size_t)n * H + y0 + p / W) * W + (p % W)) * Co + 16 * j + c;
+                    mk[i][j][r] = P.mask ? ldg(P.mask + o) : 1.f;
+                    ad[i][j][r] = P.add ? ldg(P.add + o) : 0.f;
+                }
+        }
+        f32x4 acc[2][CO_TILES];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < CO_TILES; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 9; ++t) {
+            const int toff = ((t / 3) * PW + (t % 3)) * CS;
+            for (int g = 0; g < ngroups; ++g) {
+                f32x4 a[2], b[CO_TILES];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(in_s + pbase[i] + toff + 16 * g);
+#pragma unroll
+                for (int j = 0; j < CO_TILES; ++j) b[j] = *reinterpret_cast<const f32x4*>(w_s + (16 * j + c) * WS + t * Ci + 16 * g + 4 * q);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < CO_TILES; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+            }
+        }
+        // ---- epilogue.  C layout: col = lane & 15 (channel), row = 4 q + r (pixel of the tile)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int t = wave + 4 * i;
+            if (t >= ntiles) continue;
+#pragma unroll
+            for (int j = 0; j < CO_TILES; ++j) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int p = 16 * t + 4 * q + r;
+                    const size_t o = (((size_t)n * H + y0 + p / W) * W + (p % W)) * Co + 16 * j + c;
+                    float v = acc[i][j][r] + bv[j];
+                    if (PIPE) {
+                        v = (mk[i][j][r] > 0.f) ? v : 0.f;
+                        v += ad[i][j][r];
+                    } else {
+                        if (P.mask) v = (ldg(P.mask + o) > 0.f) ? v : 0.f;
+                        if (P.add) v += ldg(P.add + o);
+                    }
+                    stg(P.out + o, v);
+                    if (P.out_relu) stg(P.out_relu + o, fmaxf(v, 0.f));
+                }
+            }
+        }
     }  // row blocks
 }
 
 __global__ __launch_bounds__(FQL_THREADS) void fql_conv3x3_kernel(const ConvArgs P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    if (P.Co == 32) conv_body<2>(P, lds);
-    else conv_body<1>(P, lds);
+    if (P.Co == 32) conv_body<2, false>(P, lds);
+    else conv_body<1, false>(P, lds);
+}
+__global__ __launch_bounds__(FQL_THREADS) void fql_conv3x3_u8_kernel(const ConvArgs P) {   // in_mode 2
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (P.Co == 32) conv_body<2, true>(P, lds);
+    else conv_body<1, true>(P, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
 // conv3x3 weight gradient: dK[t][c][o] = sum_{n,y,x} f(in[n,y+ty-1,x+tx-1,c]) dOut[n,y,x,o], db[o] = sum dOut.
 // Contraction over N H W pixels: every workgroup walks its share of the (image, row block) list with the input rows and
-// the dOut rows in LDS.  The 9 (Ci/16) (tap, input-channel tile) units are dealt round-robin to the 4 waves; a wave keeps
-// its units' 16 x Co accumulators in registers over ALL pixels the workgroup sees (no cross-wave reduction), so one
-// partial [9 Ci + 1][Co] per workgroup goes to memory and fql_conv_wgrad_reduce_kernel folds them in fixed order.
+// the dOut rows in LDS (the next block's rows are already in flight, see ConvTile).  The 9 (Ci/16) (tap, input-channel
+// tile) units are dealt round-robin to the 4 waves; a wave keeps its units' 16 x Co accumulators in registers over ALL
+// pixels the workgroup sees (no cross-wave reduction), so one partial [9 Ci + 1][Co] per workgroup goes to memory and
+// fql_conv_wgrad_reduce_kernel folds them in fixed order.
 // ------------------------------------------------------------------------------------------------
 struct ConvWgradArgs {
     const void* in;      // forward input of the convolution ([N,H,W,Ci_real] float or uint8)
@@ -170,6 +273,31 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradArgs& P, float* l
     float* d_s = lds + (R + 2) * PW * CS;    // [R W][DS]
     const int blocks_per_img = H / R;
     const int ntiles = R * W / 16;
+    ConvTile T;
+    T.in = P.in; T.in_s = in_s; T.H = H; T.W = W; T.Ci = Ci; T.Ci_real = P.Ci_real; T.R = R; T.in_mode = P.in_mode; T.CS = CS; T.PW = PW; T.tid = tid;
+    constexpr int ND = 4;   // dOut float4 per thread: R W Co / 4 / 256 <= 128 * 8 / 256
+    f32x4 dpre[ND];
+    const int dc4 = Co >> 2, dtotal = R * W * dc4;
+    auto fetch_d = [&](int n, int y0) {
+        const float* src = P.dout + ((size_t)n * H + y0) * W * Co;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int e = min(tid + i * FQL_THREADS, dtotal - 1);
+            dpre[i] = ldg4(src + (size_t)(e / dc4) * Co + 4 * (e % dc4));
+        }
+    };
+    auto commit_d = [&]() {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int e = tid + i * FQL_THREADS;
+            if (e < dtotal) *reinterpret_cast<f32x4*>(d_s + (e / dc4) * DS + 4 * (e % dc4)) = dpre[i];
+        }
+    };
+    if ((int)blockIdx.x < P.nblocks) {
+        T.fetch(blockIdx.x / blocks_per_img, (blockIdx.x % blocks_per_img) * R);
+        fetch_d(blockIdx.x / blocks_per_img, (blockIdx.x % blocks_per_img) * R);
+    }
+    T.init();
     f32x4 acc[NU][CO_TILES];
 #pragma unroll
     for (int k = 0; k < NU; ++k)
@@ -186,39 +314,15 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradArgs& P, float* l
     }
 
     for (int blk = blockIdx.x; blk < P.nblocks; blk += gridDim.x) {
-        const int n = blk / blocks_per_img, y0 = (blk % blocks_per_img) * R;
         __syncthreads();  // previous block's fragments are consumed
-        if (P.in_mode == 2) {
-            const unsigned char* src = (const unsigned char*)P.in + (size_t)n * H * W * P.Ci_real;
-            const int total = (R + 2) * PW * Ci;
-            for (int e = tid; e < total; e += FQL_THREADS) {
-                const int ci = e % Ci, px = e / Ci, xx = px % PW - 1, yy = y0 + px / PW - 1;
-                float v = 0.f;
-                if (ci < P.Ci_real && xx >= 0 && xx < W && yy >= 0 && yy < H) v = (float)src[((size_t)yy * W + xx) * P.Ci_real + ci] * (1.0f / 255.0f);
-                in_s[px * CS + ci] = v;
-            }
-        } else {
-            const float* src = (const float*)P.in + (size_t)n * H * W * Ci;
-            const int c4 = Ci >> 2, total = (R + 2) * PW * c4;
-            for (int e = tid; e < total; e += FQL_THREADS) {
-                const int cc = e % c4, px = e / c4, xx = px % PW - 1, yy = y0 + px / PW - 1;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
-                    v = ldg4(src + ((size_t)yy * W + xx) * Ci + 4 * cc);
-                    if (P.in_mode == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                }
-                *reinterpret_cast<f32x4*>(in_s + px * CS + 4 * cc) = v;
-            }
-        }
-        {
-            const float* src = P.dout + ((size_t)n * H + y0) * W * Co;
-            const int c4 = Co >> 2, total = R * W * c4;
-            for (int e = tid; e < total; e += FQL_THREADS) {
-                const int cc = e % c4, px = e / c4;
-                *reinterpret_cast<f32x4*>(d_s + px * DS + 4 * cc) = ldg4(src + (size_t)px * Co + 4 * cc);
-            }
-        }
+        T.commit();
+        commit_d();
         __syncthreads();
+        const int nxt = blk + gridDim.x;
+        if (nxt < P.nblocks) {
+            T.fetch(nxt / blocks_per_img, (nxt % blocks_per_img) * R);
+            fetch_d(nxt / blocks_per_img, (nxt % blocks_per_img) * R);
+        }
         for (int pg = 0; pg < ntiles; ++pg) {
             // B fragments: dOut[pixel 16 pg + 4 q + s][16 j + c]   (every wave reads them: they are shared by all units)
             float b[CO_TILES][4];

@@ -1392,7 +1392,8 @@ struct fql_engine {
                 case OP_CONV: {
                     const ConvArgs& a = L.op.conv;
                     const size_t lds = ((size_t)(a.R + 2) * (a.W + 2) * (a.Ci + 4) + (size_t)a.Co * (9 * a.Ci + 4)) * sizeof(float);
-                    hipLaunchKernelGGL(fql_conv3x3_kernel, dim3(std::min(a.N * (a.H / a.R), 2 * num_cus)), dim3(FQL_THREADS), lds, s, a);
+                    if (a.in_mode == 2) hipLaunchKernelGGL(fql_conv3x3_u8_kernel, dim3(std::min(a.N * (a.H / a.R), 3 * num_cus)), dim3(FQL_THREADS), lds, s, a);
+                    else hipLaunchKernelGGL(fql_conv3x3_kernel, dim3(a.N * (a.H / a.R)), dim3(FQL_THREADS), lds, s, a);
                     break;
                 }
                 case OP_POOL: {
