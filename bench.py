@@ -57,6 +57,9 @@ def main():
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--rows', type=int, default=1_000_000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', choices=['state', 'visual'], default='state',
+                    help="state = BASELINE.json configs[1] (the headline metric); visual = configs[4] (impala_small, 64x64x9 uint8)")
+    ap.add_argument('--frames', type=int, default=20_000, help='frames in the synthetic visual dataset')
     args = ap.parse_args()
 
     import torch
@@ -79,10 +82,27 @@ def main():
 
     od, ad, B = 29, 8, args.batch
     cfg = fql_amd.get_config()
-    cfg.update(alpha=10.0, batch_size=B)
-    ds = O.make_synthetic_dataset(args.rows, od, ad, seed=0)
-    agent = fql_amd.FQLAgent.create(rank, ds['observations'][:1], ds['actions'][:1], cfg)
-    agent.upload_dataset(ds)
+    visual = args.workload == 'visual'
+    if visual:
+        # BASELINE.json configs[4] / SURVEY.md 8d "Config 5": uint8 frames, frame_stack 3 -> [64, 64, 9], impala_small encoders,
+        # alpha 300, p_aug 0.5; act_dim is a runtime parameter (cube-single: 5)
+        import numpy as np
+        ad = 5
+        n = args.rows = args.frames
+        rng = np.random.default_rng(0)
+        term = (rng.random(n) < 1.0 / 200).astype(np.float32); term[-1] = 1
+        ds = {'observations': rng.integers(0, 256, size=(n, 64, 64, 3), dtype=np.uint8),
+              'next_observations': rng.integers(0, 256, size=(n, 64, 64, 3), dtype=np.uint8),
+              'actions': np.clip(rng.uniform(-1, 1, size=(n, ad)), -1 + 1e-5, 1 - 1e-5).astype(np.float32),
+              'rewards': -(rng.random(n) < 0.99).astype(np.float32), 'masks': 1 - term, 'terminals': term}
+        cfg.update(alpha=300.0, batch_size=B, encoder='impala_small')
+        agent = fql_amd.FQLAgent.create(rank, np.zeros((1, 64, 64, 9), np.uint8), ds['actions'][:1], cfg)
+        agent.upload_dataset(ds, frame_stack=3, p_aug=0.5)
+    else:
+        cfg.update(alpha=10.0, batch_size=B)
+        ds = O.make_synthetic_dataset(args.rows, od, ad, seed=0)
+        agent = fql_amd.FQLAgent.create(rank, ds['observations'][:1], ds['actions'][:1], cfg)
+        agent.upload_dataset(ds)
     stream = None if os.environ.get('FQL_BENCH_OWN_STREAM') else torch.cuda.current_stream().cuda_stream
     dp = DataParallelFQL(agent) if dist is not None else None
     lo, hi = shard_range(args.rows, rank, world)
@@ -120,23 +140,30 @@ def main():
     if rank == 0:
         steps_per_s = args.steps / dt
         flop_per_step = 2.0 * st['macs_per_update']            # algorithmic: SURVEY.md 8d (12.376 GFLOP at B=256)
-        step_us_dev = dev_ms * 1e3 / args.steps                # device time per update (HIP events)
-        achieved = flop_per_step / (step_us_dev * 1e-6) / 1e12
+        step_us_dev = dev_ms * 1e3 / args.steps                # device time per update (HIP events on the launch stream)
+        step_us_wall = dt * 1e6 / args.steps                   # fenced wall clock per update (>= device time: enqueue is async)
+        # the events bracket the launch stream only; when the graph's side lanes outlast it the wall clock is the honest
+        # duration, so the roofline is priced on the LARGER of the two
+        achieved = flop_per_step / (max(step_us_dev, step_us_wall) * 1e-6) / 1e12
         out = {
             'metric': 'FQL gradient-steps/s (batch=256)', 'value': round(steps_per_s * world, 2), 'unit': 'grad-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt * 1e3 / args.steps, 5),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'antmaze-large-shaped synthetic replay (obs=29, act=8), batch=256/GPU, hidden=512x4, '
-                                   'flow_steps=10, alpha=10, 1M device-resident transitions (BASELINE.json configs[1])',
+            'config': {'workload': ('visual-cube-shaped synthetic replay (uint8 64x64x9 = 3 stacked frames, act=5), impala_small encoders, '
+                                    f'batch={B}/GPU, hidden=512x4, flow_steps=10, alpha=300, p_aug=0.5, {args.frames} device-resident frames '
+                                    '(BASELINE.json configs[4])') if visual else
+                                   ('antmaze-large-shaped synthetic replay (obs=29, act=8), batch=256/GPU, hidden=512x4, '
+                                    'flow_steps=10, alpha=10, 1M device-resident transitions (BASELINE.json configs[1])'),
                        'parallelism': f'dp{world}', 'samples_per_s': round(steps_per_s * world * B, 1)},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), 'traffic': None,
-                         'kernel': 'whole update graph (MFMA tile kernels fql_gemm16_kernel + fql_wgrad_kernel dominate)',
-                         'flop_per_launch': flop_per_step, 'launch_us': round(step_us_dev, 3),
+                         'kernel': ('whole update graph (fql_conv3x3_kernel + fql_conv_wgrad_kernel dominate)' if visual else
+                                    'whole update graph (MFMA tile kernels fql_gemm16_kernel + fql_wgrad_kernel dominate)'),
+                         'flop_per_launch': flop_per_step, 'launch_us': round(step_us_dev, 3), 'wall_us': round(step_us_wall, 3),
                          'kernel_launches_per_update': st['launches_per_update']},
             'last_info': {k: round(v, 5) for k, v in info.items()},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not visual:
             out['cpu_baseline'] = cpu_baseline(cfg, od, ad, B)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -1747,7 +1747,25 @@ struct fql_engine {
         const int64_t os = macs(nets[NET_OS]), bc = macs(nets[NET_BC]), cr = macs(nets[NET_C0]);
         const int64_t fwd = 3 * os + (cfg.flow_steps + 1) * bc + 6 * cr;
         const int64_t bwd = 2 * (2 * cr - first(nets[NET_C0])) + (2 * bc - first(nets[NET_BC])) + (2 * os - first(nets[NET_OS])) + 2 * cr;
-        return (fwd + bwd) * (int64_t)B;
+        int64_t total = (fwd + bwd) * (int64_t)B;
+        if (visual) {
+            // encoder: 5 distinct forward image-batches per update (onestep on obs and next_obs, critic, target, bc_flow; the
+            // reference's other three encoder calls repeat one of these on the same images and parameters) and 3 backward
+            // passes = dgrad (none into the images) + wgrad; plus the MLPs' layer-0 input gradients that feed them
+            const EncNet& en = encs[ENC_C];
+            int64_t f = (int64_t)en.dense.in * en.dense.out, first_conv = 0;
+            for (size_t s = 0; s < en.stacks.size(); ++s)
+                for (size_t j = 0; j < en.stacks[s].conv.size(); ++j) {
+                    const ConvL& c = en.stacks[s].conv[j];
+                    const int H = j == 0 ? en.stacks[s].H : en.stacks[s].H / 2, W = j == 0 ? en.stacks[s].W : en.stacks[s].W / 2;
+                    const int64_t m = (int64_t)H * W * 9 * c.cin * c.cout;
+                    f += m;
+                    if (s == 0 && j == 0) first_conv = m;
+                }
+            total += (int64_t)B * (5 * f + 3 * (2 * f - first_conv));
+            total += (int64_t)B * enc_dim * (2 * (int64_t)nets[NET_C0].layers[0].out + nets[NET_BC].layers[0].out + nets[NET_OS].layers[0].out);
+        }
+        return total;
     }
 
     void free_workspace() {
@@ -1923,6 +1941,7 @@ struct fql_engine {
         d.eps2 = stage(nz->eps2, in_noise[4], (size_t)B * ad, s);
     }
     void source_from_dataset(const int64_t* idx, int batch, int64_t lo, int64_t hi, const fql_noise* nz, hipStream_t s) {
+        if (visual) { source_from_frames(idx, nullptr, batch, lo, hi, nz, s); return; }
         if (batch != B) invalid("batch_size %d does not match the engine's workspace (%d)", batch, B);
         if (!ds_obs || ds_size <= 0) throw Invalid{"no dataset uploaded (fql_dataset_upload)"};
         if (lo == 0 && hi == 0) hi = ds_size;

@@ -153,3 +153,37 @@ def test_visual_dataset_gather_stacks_frames_and_crops_like_the_reference():
     # engine-RNG sampling (indices, coin, offsets) runs and stays finite
     _, ic = a.update_from_dataset(B, want_info=True)
     assert all(np.isfinite(v) for v in ic.values())
+
+
+def test_visual_begin_end_halves_and_checkpoint_round_trip(tmp_path):
+    """The data-parallel halves (fql_update_begin / grads in the flat buffer incl. encoder leaves / fql_update_end) equal the fused
+    update; save_agent / restore_agent carry the encoder leaves (utils/flax_utils.py:162-202 layout)."""
+    import torch
+    import fql_amd
+    from fql_amd import checkpoint
+    from fql_amd.parallel import _DevView
+    cfg, batch, nz = make_visual(seed=9)
+    a = fql_amd.FQLAgent.create(4, batch['observations'][:1], batch['actions'][:1], cfg)
+    b = fql_amd.FQLAgent.create(4, batch['observations'][:1], batch['actions'][:1], cfg)
+    params = randomize_params(a.get_params(), seed=10, scale=0.05)
+    a.set_params(params); b.set_params(params)
+    _, ia = a.update(batch, noise=nz)
+    b.update_begin(batch=batch, noise=nz)
+    ptr, n = b.grad_buffer()
+    g = torch.as_tensor(_DevView(ptr, n), device='cuda')
+    torch.cuda.synchronize()
+    n_enc = sum(v.size for k, v in leaf_dict(params).items() if '/encoder/' in k and 'target' not in k)
+    assert n > n_enc > 0 and torch.isfinite(g).all() and float(g.abs().sum()) > 0
+    b.update_end()
+    pa, pb = leaf_dict(a.get_params()), leaf_dict(b.get_params())
+    for k in pa:
+        np.testing.assert_allclose(pa[k], pb[k], rtol=0, atol=1e-6, err_msg=k)
+    assert_info_close(b.read_info(), ia, rtol=1e-5, atol=1e-6)
+    checkpoint.save_agent(a, str(tmp_path), 3)
+    c = fql_amd.FQLAgent.create(99, batch['observations'][:1], batch['actions'][:1], cfg)
+    c = checkpoint.restore_agent(c, str(tmp_path), 3)
+    for k, v in pa.items():
+        np.testing.assert_array_equal(leaf_dict(c.get_params())[k], v, err_msg=k)
+    _, i1 = a.update(batch, noise=nz)
+    _, i2 = c.update(batch, noise=nz)
+    assert i1 == i2
