@@ -17,7 +17,7 @@
 // ------------------------------------------------------------------------------------------------
 struct ConvArgs {
     const void* in;       // [N,H,W,Ci_real] float, or uint8 when in_mode == 2
-    const float* Wt;      // [9][Cw_rows][Cw_cols] arena layout of the forward kernel leaf (rows = fwd in-channels padded)
+    const float* Wl;      // weights already in the kernel's LDS layout [Co][9 Ci + 4] (fql_conv_wprep_kernel, once per pass)
     const float* bias;    // [Co] or null
     float* out;           // [N,H,W,Co]
     float* out_relu;      // optional relu(out)
@@ -27,8 +27,7 @@ struct ConvArgs {
     int Ci, Ci_real;      // staged input channels (multiple of 16) and channels present in memory
     int Co;               // output channels (16 or 32)
     int in_mode;          // 0 plain, 1 relu on load, 2 uint8 / 255
-    int transposed;       // 0 forward, 1 data gradient (weights read as K[8-t][out][in])
-    int Cw_rows, Cw_cols; // arena dims of the forward leaf per tap
+    int transposed;       // 0 forward, 1 data gradient (informational: Wl is the matching layout)
     int R;                // image rows per workgroup
 };
 
@@ -127,16 +126,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
         T.init();
     }
 
-    // ---- weights -> LDS, transposed to [out channel][k]; staged once, the workgroup then walks its share of the row blocks
+    // ---- weights -> LDS ([out channel][k]); staged once, the workgroup then walks its share of the row blocks
     {
-        const int total = 9 * Ci * Co;
-        for (int e = tid; e < total; e += FQL_THREADS) {
-            const int o = e % Co, k = e / Co, t = k / Ci, ci = k - t * Ci;
-            float v;
-            if (!P.transposed) v = (ci < P.Cw_rows) ? ldg(P.Wt + ((size_t)t * P.Cw_rows + ci) * P.Cw_cols + o) : 0.f;
-            else v = (o < P.Cw_rows) ? ldg(P.Wt + ((size_t)(8 - t) * P.Cw_rows + o) * P.Cw_cols + ci) : 0.f;
-            w_s[o * WS + k] = v;
-        }
+        const int total = (Co * WS) >> 2;   // straight 16-byte copy: the layout was prepared by fql_conv_wprep_kernel
+        for (int e = tid; e < total; e += FQL_THREADS) *reinterpret_cast<f32x4*>(w_s + 4 * e) = ldg4(P.Wl + 4 * e);
     }
     const int ntiles = R * W / 16;
     int pbase[2];
@@ -556,4 +549,26 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_img_index_kernel(const ImgInd
         cx = (int)(((uint64_t)rng_u32(P.key, step, 10u, (uint32_t)b) * w) >> 32);
     }
     P.crop[2 * b] = cy; P.crop[2 * b + 1] = cx;
+}
+
+// Convolution weights from the arena leaf ([9][cin][cout], flax HWIO) into the two LDS layouts the conv kernel copies verbatim:
+//   forward  Wf[o][t Ci + c]      = K[t][c][o]        (Ci = cin padded to 16, pad columns stay zero)
+//   dgrad    Wb[c][t cout + o]    = K[8 - t][c][o]    (the flipped, transposed kernel of jax.grad's input gradient)
+// Row strides 9 Ci + 4 / 9 cout + 4.  One launch covers every convolution of an encoder (blockIdx.y = convolution).
+struct ConvWprepTask {
+    const float* K;
+    float* Wf;
+    float* Wb;   // null: no data gradient needed (first convolution)
+    int cin, cout, Ci;
+};
+__global__ __launch_bounds__(FQL_THREADS) void fql_conv_wprep_kernel(const ConvWprepTask* __restrict__ tasks) {
+    const ConvWprepTask T = tasks[blockIdx.y];
+    const int total = 9 * T.cin * T.cout;
+    const int WSf = 9 * T.Ci + 4, WSb = 9 * T.cout + 4;
+    for (int e = blockIdx.x * FQL_THREADS + threadIdx.x; e < total; e += gridDim.x * FQL_THREADS) {
+        const int o = e % T.cout, r = e / T.cout, c = r % T.cin, t = r / T.cin;
+        const float v = T.K[e];
+        T.Wf[(size_t)o * WSf + t * T.Ci + c] = v;
+        if (T.Wb) T.Wb[(size_t)c * WSb + (8 - t) * T.cout + o] = v;
+    }
 }

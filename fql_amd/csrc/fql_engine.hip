@@ -81,6 +81,7 @@ enum { NET_C0 = 0, NET_C1, NET_BC, NET_OS, NET_T0, NET_T1, NUM_NETS };
 struct ConvL {
     size_t w, b;
     int cin, cout;
+    float *Wf = nullptr, *Wb = nullptr;   // LDS-layout copies refreshed by fql_conv_wprep_kernel at the start of each pass
 };
 struct EncStack {
     std::vector<ConvL> conv;  // conv[0] at the stack's input resolution, the rest after the 2x max-pool
@@ -112,7 +113,7 @@ struct Leaf {
 // program = ordered ops with read/write sets -> levels -> launches
 // ------------------------------------------------------------------------------------------------
 enum OpType { OP_GEMM, OP_GEMM64, OP_WGRAD, OP_LNBWD, OP_PREP, OP_POSTOS, OP_EULER_FIN, OP_PEC, OP_LOSS_CRITIC, OP_LOSS_Q, OP_LOSS_BC,
-              OP_LOSS_ACTOR, OP_CONV, OP_POOL, OP_POOL_BWD, OP_CONV_WGRAD, OP_CONV_WRED, OP_ENC_DZ, OP_ADAM, OP_FINALIZE };
+              OP_LOSS_ACTOR, OP_CONV_WPREP, OP_CONV, OP_POOL, OP_POOL_BWD, OP_CONV_WGRAD, OP_CONV_WRED, OP_ENC_DZ, OP_ADAM, OP_FINALIZE };
 
 struct Op {
     OpType type;
@@ -134,6 +135,8 @@ struct Op {
     ConvWgradArgs cw;
     ConvWredArgs cwr;
     EncDzArgs edz;
+    const ConvWprepTask* wprep_tasks = nullptr;
+    int wprep_n = 0;
     int cw_grid = 0;
     int adam_c0 = 0, adam_n = -1;  // chunk range of an Adam op (-1: all chunks)
     int fin_mode = 0;
@@ -205,6 +208,9 @@ struct fql_engine {
 
     Net nets[NUM_NETS];
     EncNet encs[NUM_ENC];
+    ConvWprepTask* enc_wprep[NUM_ENC] = {nullptr, nullptr, nullptr, nullptr};   // device task tables of fql_conv_wprep_kernel
+    int enc_nconv[NUM_ENC] = {0, 0, 0, 0};
+    std::vector<void*> enc_allocs;
     bool visual = false;
     int enc_dim = 0;
     unsigned char* img_all = nullptr;   // [2B] images: obs batch, then next_obs batch (fixed address: graphs bake it in)
@@ -370,6 +376,26 @@ struct fql_engine {
                 if (L.in_p > 1024 || L.out_p > 1024) invalid("layer widths above 1024 are not supported (got %d -> %d)", L.in, L.out);
         if (nets[NET_T0].off - n_train != 0 || nets[NET_T0].size + nets[NET_T1].size + (visual ? encs[ENC_T].size : 0) != critic_size)
             invalid("internal: target arena layout mismatch");
+    }
+
+    // LDS-layout weight copies of every convolution + the task tables of fql_conv_wprep_kernel (needs P)
+    void build_enc_weights() {
+        if (!visual) return;
+        for (int ei = 0; ei < NUM_ENC; ++ei) {
+            std::vector<ConvWprepTask> tasks;
+            bool first = true;
+            for (EncStack& st : encs[ei].stacks)
+                for (ConvL& c : st.conv) {
+                    const int Ci = pad16c(c.cin);
+                    c.Wf = dalloc(enc_allocs, (size_t)c.cout * (9 * Ci + 4));
+                    c.Wb = first ? nullptr : dalloc(enc_allocs, (size_t)c.cin * (9 * c.cout + 4));   // no gradient into the images
+                    tasks.push_back(ConvWprepTask{P + c.w, c.Wf, c.Wb, c.cin, c.cout, Ci});
+                    first = false;
+                }
+            enc_nconv[ei] = (int)tasks.size();
+            enc_wprep[ei] = (ConvWprepTask*)dalloc(enc_allocs, tasks.size() * sizeof(ConvWprepTask) / sizeof(float) + 4);
+            HIP_CHECK(hipMemcpy(enc_wprep[ei], tasks.data(), tasks.size() * sizeof(ConvWprepTask), hipMemcpyHostToDevice));
+        }
     }
 
     void build_leaves() {
@@ -605,15 +631,15 @@ struct fql_engine {
         Op op{};
         op.type = OP_CONV;
         ConvArgs& a = op.conv;
-        a.in = in; a.Wt = P + c.w; a.bias = transposed ? nullptr : P + c.b;
+        a.in = in; a.Wl = transposed ? c.Wb : c.Wf; a.bias = transposed ? nullptr : P + c.b;
         a.out = out; a.out_relu = out_relu; a.mask = mask; a.add = add;
         a.N = n; a.H = H; a.W = W;
         if (!transposed) { a.Ci = pad16c(c.cin); a.Ci_real = c.cin; a.Co = c.cout; }
         else { a.Ci = c.cout; a.Ci_real = c.cout; a.Co = c.cin; }
         a.in_mode = in_mode; a.transposed = transposed ? 1 : 0;
-        a.Cw_rows = c.cin; a.Cw_cols = c.cout;
         a.R = conv_rows(H, W, a.Ci, a.Co, false);
-        op.reads = {in_id, P + c.w};
+        op.reads = {in_id, a.Wl};
+        if (!transposed) op.reads.push_back(P + c.b);
         if (mask) op.reads.push_back(mask_id);
         if (add) op.reads.push_back(add_id);
         op.writes = {out_id};
@@ -623,6 +649,19 @@ struct fql_engine {
     void emit_encoder_forward(Program& pr, EncBuf& b) {
         const EncNet& en = encs[b.enc];
         const int n = b.n;
+        {   // this pass's weights in LDS layout (forward and data-gradient forms), one small launch per encoder pass
+            Op op{};
+            op.type = OP_CONV_WPREP;
+            op.wprep_tasks = enc_wprep[b.enc];
+            op.wprep_n = enc_nconv[b.enc];
+            for (const EncStack& st : en.stacks)
+                for (const ConvL& c : st.conv) {
+                    op.reads.push_back(P + c.w);
+                    op.writes.push_back(c.Wf);
+                    if (c.Wb) op.writes.push_back(c.Wb);
+                }
+            push(pr, op);
+        }
         const float* x = nullptr;
         for (size_t s = 0; s < en.stacks.size(); ++s) {
             const EncStack& st = en.stacks[s];
@@ -1335,6 +1374,8 @@ struct fql_engine {
             static const int skip_lane = getenv("FQL_SKIP_LANE") ? atoi(getenv("FQL_SKIP_LANE")) : -1;
             if (skip_lane >= 0 && pr.two_lanes && L.lane == skip_lane && L.type != OP_PREP) continue;
             hipStream_t s = par ? ls[L.lane] : s0;
+            static const bool trace_l = getenv("FQL_TRACE") != nullptr;
+            if (trace_l) fprintf(stderr, "[fql] launch %d type %d lane %d waits %zu\n", (int)(&L - pr.launches.data()), (int)L.type, L.lane, L.waits.size());
             if (par)
                 for (int w : L.waits) if (pr.launches[w].ev) HIP_CHECK(hipStreamWaitEvent(s, pr.launches[w].ev, 0));
             switch (L.type) {
@@ -1388,6 +1429,9 @@ struct fql_engine {
                     break;
                 case OP_LOSS_ACTOR:
                     hipLaunchKernelGGL(fql_loss_actor_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.la);
+                    break;
+                case OP_CONV_WPREP:
+                    hipLaunchKernelGGL(fql_conv_wprep_kernel, dim3(4, L.op.wprep_n), dim3(FQL_THREADS), 0, s, L.op.wprep_tasks);
                     break;
                 case OP_CONV: {
                     const ConvArgs& a = L.op.conv;
@@ -1856,15 +1900,22 @@ struct fql_engine {
             for (int b = 0; b < B; ++b) h[(size_t)b * 16] = -1.0f / (2.0f * (float)B);
             for (int e = 0; e < 2; ++e) HIP_CHECK(hipMemcpy(p_c2[e].dz.back(), h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
         }
+        static const bool trace = getenv("FQL_TRACE") != nullptr;
+#define FQL_TR(msg) do { if (trace) fprintf(stderr, "[fql] %s\n", msg); } while (0)
         build_step_program(prog_fwdbwd, true);
         build_opt_program(prog_opt);
         build_step_program(prog_loss, false);
-        schedule(prog_fwdbwd, W); schedule(prog_opt, W); schedule(prog_loss, W);
-        capture(prog_fwdbwd); capture(prog_opt); capture(prog_loss);
+        FQL_TR("programs built");
+        schedule(prog_fwdbwd, W); FQL_TR("scheduled fwdbwd"); schedule(prog_opt, W); schedule(prog_loss, W);
+        FQL_TR("scheduled");
+        capture(prog_fwdbwd); FQL_TR("captured fwdbwd"); capture(prog_opt); capture(prog_loss);
+        FQL_TR("captured");
         if (getenv("FQL_NO_FULL") == nullptr) {
             build_full_program(prog_full);
             schedule(prog_full, W);
+            FQL_TR("scheduled full");
             capture(prog_full);
+            FQL_TR("captured full");
         }
         if (getenv("FQL_NO_SPLIT") == nullptr) {
             split_build = true;
@@ -2191,6 +2242,7 @@ int fql_create(const fql_config* cfg, uint64_t seed, fql_handle* out) {
         HIP_CHECK(hipMemset(h->G, 0, h->n_train * sizeof(float)));
         HIP_CHECK(hipMemset(h->Mu, 0, h->n_train * sizeof(float)));
         HIP_CHECK(hipMemset(h->Nu, 0, h->n_train * sizeof(float)));
+        h->build_enc_weights();
         h->build_leaves();
         h->init_params();
         HIP_CHECK(hipMalloc((void**)&h->d_state, sizeof(DevState)));
@@ -2224,6 +2276,7 @@ int fql_destroy(fql_handle h) {
     if (h->h_src_ring) hipHostFree(h->h_src_ring);
     hipFree(h->ds_obs); hipFree(h->ds_act); hipFree(h->ds_rew); hipFree(h->ds_mask); hipFree(h->ds_nobs); hipFree(h->ds_row);
     hipFree(h->ds_frames); hipFree(h->ds_next_frames); hipFree(h->ds_init);
+    for (void* q : h->enc_allocs) hipFree(q);
     if (h->stream) hipStreamDestroy(h->stream);
     if (h->stream2) hipStreamDestroy(h->stream2);
     if (h->stream3) hipStreamDestroy(h->stream3);
