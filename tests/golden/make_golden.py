@@ -70,5 +70,57 @@ def main():
         print(name, 'loss', float(loss), 'bytes', os.path.getsize(os.path.join(HERE, f'{name}.npz')))
 
 
+
+
+def visual_params(seed, hw, c, ad, cfg):
+    """Deterministic parameters of the visual golden case (numpy's PCG64 streams are stable across versions): the full tree
+    would be ~5 MB per copy, so the fixture stores the seed and per-leaf summaries instead of the tensors."""
+    params = O.init_params(seed, (hw, hw, c), ad, cfg, np.float64)
+    rng = np.random.default_rng(seed + 1)
+    for path, leaf in O.tree_leaves_with_path(params):
+        if path.endswith('/bias') or path.endswith('/scale'):
+            leaf += 0.05 * rng.standard_normal(leaf.shape)
+    params['modules_target_critic'] = O.tree_map(lambda a: a + 0.01 * rng.standard_normal(a.shape), params['modules_critic'])
+    return O.tree_map(lambda a: a.astype(np.float32), params)
+
+
+def visual_case():
+    """BASELINE configs[4] in miniature: uint8 [B,32,32,3] observations, impala_small encoders."""
+    name, hw, c, ad, B, hidden, seed = 'visual_small', 32, 3, 4, 16, (32, 32, 32, 32), 4242
+    cfg = O.get_config()
+    cfg.update(actor_hidden_dims=hidden, value_hidden_dims=hidden, batch_size=B, alpha=3.0, encoder='impala_small')
+    params = visual_params(seed, hw, c, ad, cfg)
+    rng = np.random.default_rng(seed + 2)
+    batch = {'observations': rng.integers(0, 256, size=(B, hw, hw, c), dtype=np.uint8),
+             'next_observations': rng.integers(0, 256, size=(B, hw, hw, c), dtype=np.uint8),
+             'actions': rng.uniform(-1, 1, size=(B, ad)).astype(np.float32),
+             'rewards': -(rng.random(B) < 0.9).astype(np.float32), 'masks': (rng.random(B) < 0.9).astype(np.float32)}
+    noise = O.make_noise(B, ad, seed + 3)
+    ref = O.OracleFQL(params, cfg, (hw, hw, c), ad, np.float64)
+    loss, info_tl = ref.total_loss(batch, noise)
+    _, _, grads = ref.grads(batch, noise)
+    sample = ref.sample_actions(batch['observations'], noise['eps2'])
+    flow = ref.compute_flow_actions(batch['observations'], noise['z'])
+    _, info_up = ref.update(batch, noise)
+    paths = [p for p, _ in O.tree_leaves_with_path(grads)]
+    out = {'meta': json.dumps(dict(hw=hw, c=c, act_dim=ad, B=B, hidden=list(hidden), seed=seed, alpha=3.0, paths=paths))}
+    for k, v in batch.items():
+        out[f'batch/{k}'] = v
+    for k, v in noise.items():
+        out[f'noise/{k}'] = v
+    out['grad_l2'] = np.array([np.sqrt(np.sum(np.square(g))) for _, g in O.tree_leaves_with_path(grads)])
+    out['grad_sum'] = np.array([np.sum(g) for _, g in O.tree_leaves_with_path(grads)])
+    out['new_param_sum'] = np.array([np.sum(v.astype(np.float64)) for _, v in O.tree_leaves_with_path(ref.params)])
+    out['total_loss'] = np.float64(loss)
+    out['info_total_loss'] = np.array([float(info_tl[k]) for k in O.INFO_KEYS[:10]])
+    out['info_update'] = np.array([float(info_up[k]) for k in O.INFO_KEYS])
+    out['sample_actions'] = sample.astype(np.float32)
+    out['flow_actions'] = flow.astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
+    print(name, 'loss', float(loss), 'bytes', os.path.getsize(os.path.join(HERE, f'{name}.npz')))
+
+
 if __name__ == '__main__':
-    main()
+    if '--visual-only' not in sys.argv:
+        main()
+    visual_case()

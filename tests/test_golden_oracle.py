@@ -8,7 +8,8 @@ import pytest
 
 from oracle import fql_oracle as O
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', '*.npz')))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), 'golden', '*.npz')) if 'visual' not in os.path.basename(p))
+VISUAL_GOLDEN = os.path.join(os.path.dirname(__file__), 'golden', 'visual_small.npz')
 
 
 def load_case(path):
@@ -58,3 +59,39 @@ def test_oracle_reproduces_golden(path, dtype, rtol):
     _, iu = ref.update(c['batch'], c['noise'])
     for i, k in enumerate(O.INFO_KEYS):
         assert abs(iu[k] - c['info_update'][i]) <= rtol * max(1, abs(c['info_update'][i])), k
+
+
+def load_visual_case():
+    """tests/golden/visual_small.npz: inputs + expected outputs; the parameters are regenerated from the stored seed."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('make_golden', os.path.join(os.path.dirname(__file__), 'golden', 'make_golden.py'))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    z = np.load(VISUAL_GOLDEN, allow_pickle=False)
+    m = json.loads(str(z['meta']))
+    cfg = O.get_config()
+    cfg.update(actor_hidden_dims=tuple(m['hidden']), value_hidden_dims=tuple(m['hidden']), batch_size=m['B'], alpha=m['alpha'],
+               encoder='impala_small')
+    params = mg.visual_params(m['seed'], m['hw'], m['c'], m['act_dim'], cfg)
+    batch = {k[6:]: z[k] for k in z.files if k.startswith('batch/')}
+    noise = {k[6:]: z[k] for k in z.files if k.startswith('noise/')}
+    return dict(meta=m, cfg=cfg, params=params, batch=batch, noise=noise, z=z)
+
+
+@pytest.mark.parametrize('dtype,rtol', [(np.float64, 1e-6), (np.float32, 5e-4)])
+def test_oracle_reproduces_visual_golden(dtype, rtol):
+    c = load_visual_case()
+    m, z = c['meta'], c['z']
+    ref = O.OracleFQL(c['params'], c['cfg'], (m['hw'], m['hw'], m['c']), m['act_dim'], dtype)
+    loss, info = ref.total_loss(c['batch'], c['noise'])
+    assert abs(loss - float(z['total_loss'])) <= rtol * abs(float(z['total_loss']))
+    _, _, g = ref.grads(c['batch'], c['noise'])
+    leaves = O.tree_leaves_with_path(g)
+    assert [p for p, _ in leaves] == m['paths']
+    l2 = np.array([np.sqrt(np.sum(np.square(v.astype(np.float64)))) for _, v in leaves])
+    np.testing.assert_allclose(l2, z['grad_l2'], rtol=20 * rtol, atol=1e-9)
+    np.testing.assert_allclose(ref.sample_actions(c['batch']['observations'], c['noise']['eps2']), z['sample_actions'], atol=2e-4 if dtype == np.float32 else 1e-6)
+    np.testing.assert_allclose(ref.compute_flow_actions(c['batch']['observations'], c['noise']['z']), z['flow_actions'], atol=2e-4 if dtype == np.float32 else 1e-6)
+    _, iu = ref.update(c['batch'], c['noise'])
+    for i, k in enumerate(O.INFO_KEYS):
+        assert abs(iu[k] - z['info_update'][i]) <= 10 * rtol * abs(z['info_update'][i]) + 1e-6, k

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import fql_oracle as O
-from tests.test_golden_oracle import GOLDEN, load_case
+from tests.test_golden_oracle import GOLDEN, load_case, load_visual_case
 
 pytestmark = pytest.mark.gpu
 
@@ -29,3 +29,27 @@ def test_engine_reproduces_golden(path):
     mu = dict(O.tree_leaves_with_path(agent.get_opt_state()['mu']))
     for p, g in O.tree_leaves_with_path(c['grads']):
         np.testing.assert_allclose(mu[p] / 0.1, g, rtol=0, atol=2e-5 * np.abs(g).max() + 1e-9, err_msg=p)
+
+
+def test_engine_reproduces_visual_golden():
+    """tests/golden/visual_small.npz (impala_small encoders on uint8 images): info scalars, per-leaf gradient norms, actions."""
+    import fql_amd
+    c = load_visual_case()
+    m, z = c['meta'], c['z']
+    agent = fql_amd.FQLAgent.create(0, c['batch']['observations'][:1], c['batch']['actions'][:1], c['cfg'])
+    agent.set_params(c['params'])
+    loss, info = agent.total_loss(c['batch'], noise=c['noise'])
+    assert abs(loss - float(z['total_loss'])) <= 2e-5 + 1e-4 * abs(float(z['total_loss']))
+    for i, k in enumerate(O.INFO_KEYS[:10]):
+        assert abs(info[k] - z['info_total_loss'][i]) <= 2e-5 + 1e-4 * abs(z['info_total_loss'][i]), k
+    np.testing.assert_allclose(agent.sample_actions(c['batch']['observations'], noises=c['noise']['eps2']), z['sample_actions'], atol=5e-6)
+    np.testing.assert_allclose(agent.compute_flow_actions(c['batch']['observations'], c['noise']['z']), z['flow_actions'], atol=2e-5)
+    _, iu = agent.update(c['batch'], noise=c['noise'])
+    for i, k in enumerate(O.INFO_KEYS):
+        assert abs(iu[k] - z['info_update'][i]) <= 2e-5 + 1e-4 * abs(z['info_update'][i]), k
+    mu = dict(O.tree_leaves_with_path(agent.get_opt_state()['mu']))
+    assert list(mu) == m['paths']
+    l2 = np.array([np.sqrt(np.sum(np.square(v.astype(np.float64) / 0.1))) for v in mu.values()])
+    # per-leaf gradient norms; loose enough for a max-pool tie-break (DESIGN.md section 2), tight for everything else
+    np.testing.assert_allclose(l2, z['grad_l2'], rtol=2e-2, atol=1e-9)
+    assert np.mean(np.abs(l2 - z['grad_l2']) <= 1e-4 * z['grad_l2'] + 1e-9) >= 0.75
