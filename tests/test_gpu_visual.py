@@ -187,3 +187,47 @@ def test_visual_begin_end_halves_and_checkpoint_round_trip(tmp_path):
     _, i1 = a.update(batch, noise=nz)
     _, i2 = c.update(batch, noise=nz)
     assert i1 == i2
+
+
+def test_visual_full_size_is_deterministic_and_consistent():
+    """BASELINE configs[4] at full size (64x64x9 uint8, B=256, impala_small, hidden 512x4): the oracle would take minutes
+    here, so size-independent properties instead: two engines on the same bytes agree bitwise (no atomics anywhere),
+    total_loss == the loss terms update() reports for the same step, and the frames gather with identity crop reproduces an
+    explicitly stacked batch."""
+    import fql_amd
+    from oracle import encoder_oracle as E
+    B, ad, fs, n = 256, 5, 3, 600
+    cfg = fql_amd.get_config()
+    cfg.update(encoder='impala_small', alpha=300.0, batch_size=B)
+    rng = np.random.default_rng(21)
+    frames = rng.integers(0, 256, size=(n, 64, 64, 3), dtype=np.uint8)
+    nxt = rng.integers(0, 256, size=(n, 64, 64, 3), dtype=np.uint8)
+    term = (rng.random(n) < 0.02).astype(np.float32); term[-1] = 1
+    ds = {'observations': frames, 'next_observations': nxt, 'terminals': term, 'masks': 1 - term,
+          'actions': rng.uniform(-1, 1, size=(n, ad)).astype(np.float32), 'rewards': -np.ones(n, np.float32)}
+    ex = np.zeros((1, 64, 64, 9), np.uint8)
+    a = fql_amd.FQLAgent.create(7, ex, ds['actions'][:1], cfg)
+    b = fql_amd.FQLAgent.create(7, ex, ds['actions'][:1], cfg)
+    pa = leaf_dict(a.get_params())
+    for k, v in leaf_dict(b.get_params()).items():
+        np.testing.assert_array_equal(v, pa[k])                              # same seed -> same init
+    assert pa['modules_critic/encoder/MLP_0/Dense_0/kernel'].shape == (2048, 512)
+    a.upload_dataset(ds, frame_stack=fs, p_aug=0.0)
+    idxs = rng.integers(0, n, size=B)
+    nz = O.make_noise(B, ad, 22)
+    obs, nobs = E.stack_frames(frames, nxt, term, idxs, fs)
+    batch = {'observations': obs, 'next_observations': nobs, 'actions': ds['actions'][idxs], 'rewards': ds['rewards'][idxs],
+             'masks': ds['masks'][idxs]}
+    loss, itl = b.total_loss(batch, None, noise=nz)
+    _, ia = a.update_from_dataset(B, idxs=idxs, noise=nz, want_info=True)
+    _, ib = b.update(batch, noise=nz)
+    assert ia == ib
+    assert all(np.isfinite(v) for v in ia.values())
+    for k in ('critic/critic_loss', 'actor/actor_loss', 'actor/bc_flow_loss', 'actor/distill_loss', 'actor/q_loss', 'actor/mse'):
+        assert itl[k] == ib[k], k                                            # same kernels, same inputs: bitwise
+    assert abs(loss - (ib['critic/critic_loss'] + ib['actor/actor_loss'])) <= 1e-5 * abs(loss)
+    pa, pb = leaf_dict(a.get_params()), leaf_dict(b.get_params())
+    for k in pa:
+        np.testing.assert_array_equal(pa[k], pb[k], err_msg=k)
+    moved = [k for k in pa if not k.startswith('modules_target') and k.endswith('kernel')]
+    assert all(np.abs(pa[k]).sum() > 0 for k in moved)
