@@ -29,6 +29,7 @@ struct ConvArgs {
     int in_mode;          // 0 plain, 1 relu on load, 2 uint8 / 255
     int transposed;       // 0 forward, 1 data gradient (informational: Wl is the matching layout)
     int R;                // image rows per workgroup
+    int tile0, nwg;       // first workgroup of this task inside a shared launch, and how many it has
 };
 
 // Input rows y0-1 .. y0+R of image n (zero halo) -> LDS [(R+2)][(W+2)][Ci+4], in two halves so the global loads of the NEXT
@@ -119,10 +120,11 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
     float* w_s = lds + (R + 2) * PW * CS;              // [Co][WS]
     const int blocks_per_img = H / R;
     const int nblocks = P.N * blocks_per_img;
+    const int wg = (int)blockIdx.x - P.tile0, nwg = P.nwg;   // this task's workgroups walk its row blocks with stride nwg
     ConvTile T;
     T.in = P.in; T.in_s = in_s; T.H = H; T.W = W; T.Ci = Ci; T.Ci_real = P.Ci_real; T.R = R; T.in_mode = P.in_mode; T.CS = CS; T.PW = PW; T.tid = tid;
     if constexpr (PIPE) {
-        T.fetch(blockIdx.x / blocks_per_img, (blockIdx.x % blocks_per_img) * R);
+        T.fetch(wg / blocks_per_img, (wg % blocks_per_img) * R);
         T.init();
     }
 
@@ -144,7 +146,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
     for (int j = 0; j < CO_TILES; ++j) bv[j] = P.bias ? ldg(P.bias + 16 * j + c) : 0.f;
     const int ngroups = Ci >> 4;
 
-    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    for (int blk = wg; blk < nblocks; blk += nwg) {
         const int n = blk / blocks_per_img, y0 = (blk % blocks_per_img) * R;
         __syncthreads();  // the previous block's fragments are consumed (first pass: the zero fill / weights are in place)
         if constexpr (PIPE) {
@@ -163,7 +165,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
             }
         }
         __syncthreads();
-        const int nxt = blk + gridDim.x;
+        const int nxt = blk + nwg;
         if constexpr (PIPE) { if (nxt < nblocks) T.fetch(nxt / blocks_per_img, (nxt % blocks_per_img) * R); }
         // epilogue operands of this block: issued now, consumed after the MFMA loop
         float mk[2][CO_TILES][4], ad[2][CO_TILES][4];
@@ -229,13 +231,16 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
     }  // row blocks
 }
 
-__global__ __launch_bounds__(FQL_THREADS) void fql_conv3x3_kernel(const ConvArgs P) {
+// One launch = every convolution of one scheduling level (e.g. the same layer of the four encoder passes): task table in HBM.
+__global__ __launch_bounds__(FQL_THREADS) void fql_conv3x3_kernel(const ConvArgs* __restrict__ tasks, int ntasks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const ConvArgs& P = tasks[find_task(tasks, ntasks, blockIdx.x)];
     if (P.Co == 32) conv_body<2, false>(P, lds);
     else conv_body<1, false>(P, lds);
 }
-__global__ __launch_bounds__(FQL_THREADS) void fql_conv3x3_u8_kernel(const ConvArgs P) {   // in_mode 2
+__global__ __launch_bounds__(FQL_THREADS) void fql_conv3x3_u8_kernel(const ConvArgs* __restrict__ tasks, int ntasks) {   // in_mode 2
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const ConvArgs& P = tasks[find_task(tasks, ntasks, blockIdx.x)];
     if (P.Co == 32) conv_body<2, true>(P, lds);
     else conv_body<1, true>(P, lds);
 }
@@ -253,6 +258,7 @@ struct ConvWgradArgs {
     const float* dout;   // [N,H,W,Co]
     float* partial;      // [gridDim.x][9 Ci + 1][Co]   (last row: bias partial)
     int N, H, W, Ci, Ci_real, Co, in_mode, R, nblocks;
+    int tile0, nwg;
 };
 
 template <int CI_TILES, int CO_TILES>
@@ -286,9 +292,10 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradArgs& P, float* l
             if (e < dtotal) *reinterpret_cast<f32x4*>(d_s + (e / dc4) * DS + 4 * (e % dc4)) = dpre[i];
         }
     };
-    if ((int)blockIdx.x < P.nblocks) {
-        T.fetch(blockIdx.x / blocks_per_img, (blockIdx.x % blocks_per_img) * R);
-        fetch_d(blockIdx.x / blocks_per_img, (blockIdx.x % blocks_per_img) * R);
+    const int wg = (int)blockIdx.x - P.tile0, nwg = P.nwg;
+    if (wg < P.nblocks) {
+        T.fetch(wg / blocks_per_img, (wg % blocks_per_img) * R);
+        fetch_d(wg / blocks_per_img, (wg % blocks_per_img) * R);
     }
     T.init();
     f32x4 acc[NU][CO_TILES];
@@ -306,12 +313,12 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradArgs& P, float* l
         uoff[k] = ((t / 3) * PW + (t % 3)) * CS + 16 * i + c;
     }
 
-    for (int blk = blockIdx.x; blk < P.nblocks; blk += gridDim.x) {
+    for (int blk = wg; blk < P.nblocks; blk += nwg) {
         __syncthreads();  // previous block's fragments are consumed
         T.commit();
         commit_d();
         __syncthreads();
-        const int nxt = blk + gridDim.x;
+        const int nxt = blk + nwg;
         if (nxt < P.nblocks) {
             T.fetch(nxt / blocks_per_img, (nxt % blocks_per_img) * R);
             fetch_d(nxt / blocks_per_img, (nxt % blocks_per_img) * R);
@@ -348,7 +355,7 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradArgs& P, float* l
         }
     }
     // ---- per-workgroup partial: rows k = t Ci + 16 i + 4 q + r, cols 16 j + c
-    float* out = P.partial + (size_t)blockIdx.x * (size_t)(9 * Ci + 1) * Co;
+    float* out = P.partial + (size_t)wg * (size_t)(9 * Ci + 1) * Co;
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
         const int u = wave + 4 * k;
@@ -370,8 +377,9 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradArgs& P, float* l
     }
 }
 
-__global__ __launch_bounds__(FQL_THREADS) void fql_conv_wgrad_kernel(const ConvWgradArgs P) {
+__global__ __launch_bounds__(FQL_THREADS) void fql_conv_wgrad_kernel(const ConvWgradArgs* __restrict__ tasks, int ntasks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const ConvWgradArgs& P = tasks[find_task(tasks, ntasks, blockIdx.x)];
     if (P.Ci == 32 && P.Co == 32) conv_wgrad_body<2, 2>(P, lds);
     else if (P.Ci == 16 && P.Co == 32) conv_wgrad_body<1, 2>(P, lds);
     else if (P.Ci == 32 && P.Co == 16) conv_wgrad_body<2, 1>(P, lds);
@@ -385,11 +393,13 @@ struct ConvWredArgs {
     float* dK;
     float* db;
     int nparts, Ci, Co, Cw_rows;
+    int tile0;
 };
-__global__ __launch_bounds__(FQL_THREADS) void fql_conv_wgrad_reduce_kernel(const ConvWredArgs P) {
+__global__ __launch_bounds__(FQL_THREADS) void fql_conv_wgrad_reduce_kernel(const ConvWredArgs* __restrict__ tasks, int ntasks) {
     __shared__ float red[4][64];
+    const ConvWredArgs& P = tasks[find_task(tasks, ntasks, blockIdx.x)];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int e = blockIdx.x * 64 + lane;
+    const int e = ((int)blockIdx.x - P.tile0) * 64 + lane;
     const int rows = 9 * P.Ci + 1, total = rows * P.Co;
     const size_t stride = (size_t)total;
     float s0 = 0.f, s1 = 0.f;

@@ -113,7 +113,7 @@ struct Leaf {
 // program = ordered ops with read/write sets -> levels -> launches
 // ------------------------------------------------------------------------------------------------
 enum OpType { OP_GEMM, OP_GEMM64, OP_WGRAD, OP_LNBWD, OP_PREP, OP_POSTOS, OP_EULER_FIN, OP_PEC, OP_LOSS_CRITIC, OP_LOSS_Q, OP_LOSS_BC,
-              OP_LOSS_ACTOR, OP_CONV_WPREP, OP_CONV, OP_POOL, OP_POOL_BWD, OP_CONV_WGRAD, OP_CONV_WRED, OP_ENC_DZ, OP_ADAM, OP_FINALIZE };
+              OP_LOSS_ACTOR, OP_CONV_WPREP, OP_CONV, OP_CONV_U8, OP_POOL, OP_POOL_BWD, OP_CONV_WGRAD, OP_CONV_WRED, OP_ENC_DZ, OP_ADAM, OP_FINALIZE };
 
 struct Op {
     OpType type;
@@ -192,7 +192,9 @@ struct EncBuf {
     std::vector<St> st;
     float *frelu = nullptr, *z = nullptr, *E = nullptr;   // [n, flat], [n, enc_dim] x 2
     // backward scratch (allocated only for differentiated passes)
-    float *dz = nullptr, *dA = nullptr, *dB = nullptr, *dC = nullptr, *wpart = nullptr;
+    float *dz = nullptr, *dA = nullptr, *dB = nullptr, *dC = nullptr;
+    std::map<const void*, float*> wpart;   // per convolution (keyed by its arena weight pointer): weight-gradient partials, so the
+                                            // wgrads of a pass are independent and their folds share launches
 };
 
 }  // namespace
@@ -612,7 +614,8 @@ struct fql_engine {
         if (bwd) {
             b.dz = dalloc(owner, (size_t)n * enc_dim);
             b.dA = dalloc(owner, maxel); b.dB = dalloc(owner, maxel); b.dC = dalloc(owner, maxel);
-            b.wpart = dalloc(owner, (size_t)256 * (9 * 32 + 1) * 32);
+            for (const EncStack& st : en.stacks)
+                for (const ConvL& c : st.conv) b.wpart[P + c.w] = dalloc(owner, (size_t)256 * (9 * pad16c(c.cin) + 1) * c.cout);
         }
         return b;
     }
@@ -629,7 +632,7 @@ struct fql_engine {
     void emit_conv(Program& pr, const void* in, const void* in_id, int in_mode, int n, int H, int W, const ConvL& c, bool transposed,
                    float* out, const void* out_id, float* out_relu, const float* mask, const void* mask_id, const float* add, const void* add_id) {
         Op op{};
-        op.type = OP_CONV;
+        op.type = in_mode == 2 ? OP_CONV_U8 : OP_CONV;
         ConvArgs& a = op.conv;
         a.in = in; a.Wl = transposed ? c.Wb : c.Wf; a.bias = transposed ? nullptr : P + c.b;
         a.out = out; a.out_relu = out_relu; a.mask = mask; a.add = add;
@@ -707,23 +710,24 @@ struct fql_engine {
         Op op{};
         op.type = OP_CONV_WGRAD;
         ConvWgradArgs& a = op.cw;
-        a.in = in; a.dout = dout; a.partial = b.wpart;
+        float* wp = b.wpart.at(P + c.w);
+        a.in = in; a.dout = dout; a.partial = wp;
         a.N = n; a.H = H; a.W = W; a.Ci = pad16c(c.cin); a.Ci_real = c.cin; a.Co = c.cout; a.in_mode = in_mode;
         a.R = conv_rows(H, W, a.Ci, a.Co, true);
         a.nblocks = n * (H / a.R);
         op.cw_grid = std::min(a.nblocks, 256);
         op.reads = {in_id, dout_id};
-        op.writes = {b.wpart};
+        op.writes = {wp};
         push(pr, op);
         Op r{};
         r.type = OP_CONV_WRED;
-        r.cwr = ConvWredArgs{b.wpart, G + c.w, G + c.b, op.cw_grid, a.Ci, a.Co, c.cin};
-        r.reads = {b.wpart};
+        r.cwr = ConvWredArgs{wp, G + c.w, G + c.b, op.cw_grid, a.Ci, a.Co, c.cin, 0};
+        r.reads = {wp};
         r.writes = {G + c.w, G + c.b};
         push(pr, r);
     }
     // backward of images [img0, img0 + n) of pass b; the encoding's gradient = first enc_dim columns of dxa (+ dxb)
-    void emit_encoder_backward(Program& pr, EncBuf& b, int img0, int n, const float* dxa, const float* dxb, int ld) {
+    void emit_encoder_backward(Program& pr, EncBuf& b, int img0, int n, const float* dxa, const float* dxb, int ld, const void* align_with = nullptr) {
         const EncNet& en = encs[b.enc];
         const Layer& D = en.dense;
         {
@@ -732,6 +736,9 @@ struct fql_engine {
             op.edz = EncDzArgs{dxa, dxb, b.z + (size_t)img0 * enc_dim, b.dz, n, enc_dim, ld};
             op.reads = {dxa, b.z};
             if (dxb) op.reads.push_back(dxb);
+            // level alignment: the three encoder backward passes start together so that their per-level convolutions,
+            // weight gradients and partial folds share launches (the lane is serial either way)
+            if (align_with) op.reads.push_back(align_with);
             op.writes = {b.dz};
             push(pr, op);
         }
@@ -1234,6 +1241,56 @@ struct fql_engine {
                 if (sel.empty()) continue;
                 if (lane >= 1) pr.two_lanes = true;
                 pr.lane_used[lane] = true;
+                if (ty == OP_CONV || ty == OP_CONV_U8 || ty == OP_CONV_WGRAD || ty == OP_CONV_WRED) {
+                    // every convolution-family op of this level and lane shares ONE launch (e.g. the same layer of the four
+                    // encoder passes): arg structs in an HBM table, workgroup ranges by tile0
+                    Launch L;
+                    L.type = (OpType)ty;
+                    L.lane = lane;
+                    for (const Op* o : sel) launch_of[o - pr.ops.data()] = (int)pr.launches.size();
+                    L.ntasks = (int)sel.size();
+                    int tile = 0;
+                    auto up = [&](const void* src, size_t bytes) {
+                        void* d = dalloc(owner, bytes / sizeof(float) + 4);
+                        HIP_CHECK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+                        return d;
+                    };
+                    if (ty == OP_CONV || ty == OP_CONV_U8) {
+                        std::vector<ConvArgs> tb;
+                        for (const Op* o : sel) {
+                            ConvArgs a = o->conv;
+                            const int nb = a.N * (a.H / a.R);
+                            a.tile0 = tile;
+                            a.nwg = ty == OP_CONV_U8 ? std::min(nb, std::max(1, 3 * num_cus / (int)sel.size())) : nb;
+                            tile += a.nwg;
+                            L.lds = std::max(L.lds, ((size_t)(a.R + 2) * (a.W + 2) * (a.Ci + 4) + (size_t)a.Co * (9 * a.Ci + 4)) * sizeof(float));
+                            tb.push_back(a);
+                        }
+                        L.table = up(tb.data(), tb.size() * sizeof(ConvArgs));
+                    } else if (ty == OP_CONV_WGRAD) {
+                        std::vector<ConvWgradArgs> tb;
+                        for (const Op* o : sel) {
+                            ConvWgradArgs a = o->cw;
+                            a.tile0 = tile; a.nwg = o->cw_grid;
+                            tile += a.nwg;
+                            L.lds = std::max(L.lds, ((size_t)(a.R + 2) * (a.W + 2) * (a.Ci + 4) + (size_t)a.R * a.W * (a.Co + 4)) * sizeof(float));
+                            tb.push_back(a);
+                        }
+                        L.table = up(tb.data(), tb.size() * sizeof(ConvWgradArgs));
+                    } else {
+                        std::vector<ConvWredArgs> tb;
+                        for (const Op* o : sel) {
+                            ConvWredArgs a = o->cwr;
+                            a.tile0 = tile;
+                            tile += ((9 * a.Ci + 1) * a.Co + 63) / 64;
+                            tb.push_back(a);
+                        }
+                        L.table = up(tb.data(), tb.size() * sizeof(ConvWredArgs));
+                    }
+                    L.grid = tile;
+                    pr.launches.push_back(L);
+                    continue;
+                }
                 if (!is_table((OpType)ty)) {
                     for (const Op* o : sel) {
                         Launch L;
@@ -1433,13 +1490,12 @@ struct fql_engine {
                 case OP_CONV_WPREP:
                     hipLaunchKernelGGL(fql_conv_wprep_kernel, dim3(4, L.op.wprep_n), dim3(FQL_THREADS), 0, s, L.op.wprep_tasks);
                     break;
-                case OP_CONV: {
-                    const ConvArgs& a = L.op.conv;
-                    const size_t lds = ((size_t)(a.R + 2) * (a.W + 2) * (a.Ci + 4) + (size_t)a.Co * (9 * a.Ci + 4)) * sizeof(float);
-                    if (a.in_mode == 2) hipLaunchKernelGGL(fql_conv3x3_u8_kernel, dim3(std::min(a.N * (a.H / a.R), 3 * num_cus)), dim3(FQL_THREADS), lds, s, a);
-                    else hipLaunchKernelGGL(fql_conv3x3_kernel, dim3(a.N * (a.H / a.R)), dim3(FQL_THREADS), lds, s, a);
+                case OP_CONV:
+                    hipLaunchKernelGGL(fql_conv3x3_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
                     break;
-                }
+                case OP_CONV_U8:
+                    hipLaunchKernelGGL(fql_conv3x3_u8_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
+                    break;
                 case OP_POOL: {
                     const PoolArgs& a = L.op.pool;
                     const size_t tot = (size_t)a.N * (a.H / 2) * (a.W / 2) * (a.C / 4);
@@ -1452,18 +1508,12 @@ struct fql_engine {
                     hipLaunchKernelGGL(fql_maxpool_bwd_kernel, dim3((unsigned)((tot + FQL_THREADS - 1) / FQL_THREADS)), dim3(FQL_THREADS), 0, s, a);
                     break;
                 }
-                case OP_CONV_WGRAD: {
-                    const ConvWgradArgs& a = L.op.cw;
-                    const size_t lds = ((size_t)(a.R + 2) * (a.W + 2) * (a.Ci + 4) + (size_t)a.R * a.W * (a.Co + 4)) * sizeof(float);
-                    hipLaunchKernelGGL(fql_conv_wgrad_kernel, dim3(L.op.cw_grid), dim3(FQL_THREADS), lds, s, a);
+                case OP_CONV_WGRAD:
+                    hipLaunchKernelGGL(fql_conv_wgrad_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvWgradArgs*)L.table, L.ntasks);
                     break;
-                }
-                case OP_CONV_WRED: {
-                    const ConvWredArgs& a = L.op.cwr;
-                    const int tot = (9 * a.Ci + 1) * a.Co;
-                    hipLaunchKernelGGL(fql_conv_wgrad_reduce_kernel, dim3((tot + 63) / 64), dim3(FQL_THREADS), 0, s, a);
+                case OP_CONV_WRED:
+                    hipLaunchKernelGGL(fql_conv_wgrad_reduce_kernel, dim3(L.grid), dim3(FQL_THREADS), 0, s, (const ConvWredArgs*)L.table, L.ntasks);
                     break;
-                }
                 case OP_ENC_DZ: {
                     const EncDzArgs& a = L.op.edz;
                     hipLaunchKernelGGL(fql_enc_dz_kernel, dim3((a.M * a.n + FQL_THREADS - 1) / FQL_THREADS), dim3(FQL_THREADS), 0, s, a);
@@ -1644,7 +1694,9 @@ struct fql_engine {
         }
         if (with_grads)
             for (int e = 0; e < 2; ++e) emit_backward(pr, p_c1[e], 0, B, true, visual);
-        if (with_grads && visual) {   // the critic's encoder sees the critic loss only (the actor loss uses stored params)
+        // (not in the data-parallel split program: there lane 1 must finish bucket 0 without waiting for lane 0's tail)
+        const bool enc_align = getenv("FQL_NO_ENC_ALIGN") == nullptr && !split_build;
+        if (with_grads && visual && !enc_align) {   // the critic's encoder sees the critic loss only (the actor loss uses stored params)
             place("enc", 1, true);
             emit_encoder_backward(pr, eb_c, 0, B, p_c1[0].dx0, p_c1[1].dx0, nets[NET_C0].in_p());
         }
@@ -1661,7 +1713,7 @@ struct fql_engine {
             push(pr, op);
         }
         if (with_grads) emit_backward(pr, p_bc, 0, B, true, visual);
-        if (with_grads && visual) {
+        if (with_grads && visual && !enc_align) {
             place("enc", 1, true);
             emit_encoder_backward(pr, eb_bc, 0, B, p_bc.dx0, nullptr, nets[NET_BC].in_p());
         }
@@ -1710,6 +1762,10 @@ struct fql_engine {
         if (with_grads && visual) {   // the obs half of the [obs ; next_obs] pass
             place("enc", 1, true);
             emit_encoder_backward(pr, eb_os, 0, B, p_os_bwd.dx0, nullptr, nets[NET_OS].in_p());
+            if (enc_align) {   // all three encoder backward passes level-aligned with the last one: their ops share launches
+                emit_encoder_backward(pr, eb_c, 0, B, p_c1[0].dx0, p_c1[1].dx0, nets[NET_C0].in_p(), p_os_bwd.dx0);
+                emit_encoder_backward(pr, eb_bc, 0, B, p_bc.dx0, nullptr, nets[NET_BC].in_p(), p_os_bwd.dx0);
+            }
         }
         if (!with_grads) {
             Op op{};
