@@ -458,9 +458,14 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
         for (int pass = 0; pass < TMT; ++pass) {
             const int r = 16 * pass + (tid >> 4);
             float s = 0.f, s2 = 0.f;
-            for (int k = j; k < width; k += 16) {
-                const float v = lds[r * S + k];
-                s += v; s2 += v * v;
+            // batches of 8 independent reads / loads: a rolled loop would pay one LDS (or, below, L2) round trip per element
+            for (int kb = j; kb < width; kb += 128) {
+                float xv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xv[i] = lds[r * S + min(kb + 16 * i, width - 1)];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (kb + 16 * i < width) { s += xv[i]; s2 += xv[i] * xv[i]; }
             }
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) {
@@ -471,11 +476,22 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
             const float mean = s * inv;
             const float var = fmaxf(0.0f, s2 * inv - mean * mean);
             const float rstd = 1.0f / sqrtf(var + 1e-6f);
-            for (int k = j; k < K; k += 16) {
-                float v = 0.f;
-                if (k < width) v = (lds[r * S + k] - mean) * rstd * ldg(T.ln_g + k) + ldg(T.ln_b + k);
-                lds[r * S + k] = v;
-                if (wr) stg(T.ln_xout + (size_t)(row0 + r) * T.lda + k, v);
+            for (int kb = j; kb < K; kb += 128) {
+                float xv[8], gv[8], bv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int kc = min(kb + 16 * i, width - 1);
+                    gv[i] = ldg(T.ln_g + kc); bv[i] = ldg(T.ln_b + kc);
+                    xv[i] = lds[r * S + kc];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int k = kb + 16 * i;
+                    if (k >= K) continue;
+                    const float v = (k < width) ? (xv[i] - mean) * rstd * gv[i] + bv[i] : 0.f;
+                    lds[r * S + k] = v;
+                    if (wr) stg(T.ln_xout + (size_t)(row0 + r) * T.lda + k, v);
+                }
             }
             if (wr && j == 0) {
                 stg(T.ln_stats + 2 * (row0 + r), mean);
