@@ -42,13 +42,26 @@ struct ConvTile {
     const void* in;
     float* in_s;
     int H, W, Ci, Ci_real, R, in_mode, CS, PW, tid;
+    static constexpr int NU8 = 4;   // dwords per thread on the uint8 path: (R + 2) W C / 4 / 256 <= 4 (W C <= 1152 at R = 1, 576 at R = 2)
     f32x4 pre[NF];
-    unsigned prew[NF];
+    unsigned prew[NU8];
+    int u8off[NU8][4];   // LDS offsets of the 4 bytes of each of this thread's dwords: the same for every row block
     int y0;
     __device__ __forceinline__ void init() {
         if (in_mode == 2) {
             const int total = (R + 2) * PW * CS;
             for (int e = tid; e < total; e += FQL_THREADS) in_s[e] = 0.f;
+            const int dpr = (W * Ci_real) >> 2, tdw = (R + 2) * dpr;
+#pragma unroll
+            for (int i = 0; i < NU8; ++i) {
+                const int e = min(tid + i * FQL_THREADS, tdw - 1);
+                const int rr = e / dpr, cd = e - rr * dpr;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int bi = 4 * cd + k, x = bi / Ci_real, ch = bi - x * Ci_real;
+                    u8off[i][k] = (rr * PW + x + 1) * CS + ch;
+                }
+            }
         }
     }
     __device__ __forceinline__ void fetch(int n, int y0_) {
@@ -57,7 +70,7 @@ struct ConvTile {
             const int dpr = (W * Ci_real) >> 2, total = (R + 2) * dpr;   // dwords per image row
             const unsigned* src = (const unsigned*)((const unsigned char*)in + (size_t)n * H * W * Ci_real);
 #pragma unroll
-            for (int i = 0; i < NF; ++i) {
+            for (int i = 0; i < NU8; ++i) {
                 const int e = min(tid + i * FQL_THREADS, total - 1);
                 const int rr = e / dpr, cd = e - rr * dpr;
                 const int yy = min(max(y0 + rr - 1, 0), H - 1);
@@ -79,17 +92,13 @@ struct ConvTile {
         if (in_mode == 2) {
             const int dpr = (W * Ci_real) >> 2, total = (R + 2) * dpr;
 #pragma unroll
-            for (int i = 0; i < NF; ++i) {
+            for (int i = 0; i < NU8; ++i) {
                 const int e = tid + i * FQL_THREADS;
                 if (e >= total) continue;
-                const int rr = e / dpr, cd = e - rr * dpr;
-                const int yy = y0 + rr - 1;
+                const int yy = y0 + e / dpr - 1;
                 const bool ok = yy >= 0 && yy < H;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int bi = 4 * cd + k, x = bi / Ci_real, ch = bi - x * Ci_real;
-                    in_s[(rr * PW + x + 1) * CS + ch] = ok ? (float)((prew[i] >> (8 * k)) & 255u) * (1.0f / 255.0f) : 0.f;
-                }
+                for (int k = 0; k < 4; ++k) in_s[u8off[i][k]] = ok ? (float)((prew[i] >> (8 * k)) & 255u) * (1.0f / 255.0f) : 0.f;
             }
         } else {
             const int c4 = Ci >> 2, total = (R + 2) * PW * c4;

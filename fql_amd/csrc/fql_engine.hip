@@ -1557,8 +1557,16 @@ struct fql_engine {
             if (g) hipGraphDestroy(g);
             throw;
         }
+        static const bool trace_c = getenv("FQL_TRACE") != nullptr;
+        if (trace_c) fprintf(stderr, "[fql] end capture\n");
         HIP_CHECK(hipStreamEndCapture(stream, &pr.graph));
+        if (trace_c) {
+            size_t nn = 0;
+            hipGraphGetNodes(pr.graph, nullptr, &nn);
+            fprintf(stderr, "[fql] instantiate (%zu nodes)\n", nn);
+        }
         HIP_CHECK(hipGraphInstantiate(&pr.exec, pr.graph, nullptr, nullptr, 0));
+        if (trace_c) fprintf(stderr, "[fql] instantiated\n");
     }
 
     // one graph per segment: seg 0 = lane-0 launches up to the last one lane 1 waits on, seg 1 = lane 1, seg 2 = lane 0 up to
@@ -2258,6 +2266,11 @@ int fql_create(const fql_config* cfg, uint64_t seed, fql_handle* out) {
             if (cfg->img_h <= 0 || cfg->img_w <= 0 || cfg->img_h % 32 || cfg->img_w % 32 || cfg->img_w > 128 || cfg->img_c <= 0 || cfg->img_c > 16)
                 invalid("image shape must be [H, W, C] with H, W multiples of 32 (W <= 128) and C <= 16 (got %d, %d, %d)", cfg->img_h,
                         cfg->img_w, cfg->img_c);
+            {   // the uint8 first layer stages (R + 2) image rows as <= 4 dwords per thread (ConvTile::NU8)
+                const int R0 = std::min(cfg->img_h, std::max(1, 128 / cfg->img_w));
+                if ((R0 + 2) * cfg->img_w * cfg->img_c > 4096 || (cfg->img_w * cfg->img_c) % 4)
+                    invalid("image rows of %d x %d channels are too wide for the first-layer kernel", cfg->img_w, cfg->img_c);
+            }
             h->visual = true;
             h->enc_dim = 512;          // mlp_hidden_dims = (512,) (utils/encoders.py:69)
             h->cfg.obs_dim = h->enc_dim;
