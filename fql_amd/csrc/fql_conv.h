@@ -46,6 +46,7 @@ struct ConvTile {
     f32x4 pre[NF];
     unsigned prew[NU8];
     int u8off[NU8][4];   // LDS offsets of the 4 bytes of each of this thread's dwords: the same for every row block
+    int f_lds[NF], f_g[NF], f_rr[NF];   // float path: LDS offset, offset inside an image row, tile row (-1: not this thread's); f_g < 0: halo column
     int y0;
     __device__ __forceinline__ void init() {
         if (in_mode == 2) {
@@ -62,6 +63,17 @@ struct ConvTile {
                     u8off[i][k] = (rr * PW + x + 1) * CS + ch;
                 }
             }
+        } else {
+            const int c4 = Ci >> 2, total = (R + 2) * PW * c4;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int e = tid + i * FQL_THREADS;
+                const int ec = min(e, total - 1);
+                const int cc = ec % c4, px = ec / c4, xx = px % PW - 1;
+                f_lds[i] = px * CS + 4 * cc;
+                f_rr[i] = e < total ? px / PW : -1;
+                f_g[i] = (xx >= 0 && xx < W) ? xx * Ci + 4 * cc : -1;
+            }
         }
     }
     __device__ __forceinline__ void fetch(int n, int y0_) {
@@ -77,14 +89,11 @@ struct ConvTile {
                 prew[i] = __builtin_nontemporal_load(src + (size_t)yy * dpr + cd);
             }
         } else {
-            const int c4 = Ci >> 2, total = (R + 2) * PW * c4;
             const float* src = (const float*)in + (size_t)n * H * W * Ci;
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
-                const int e = min(tid + i * FQL_THREADS, total - 1);
-                const int cc = e % c4, px = e / c4;
-                const int xx = min(max(px % PW - 1, 0), W - 1), yy = min(max(y0 + px / PW - 1, 0), H - 1);
-                pre[i] = ldg4(src + ((size_t)yy * W + xx) * Ci + 4 * cc);
+                const int yy = min(max(y0 + max(f_rr[i], 0) - 1, 0), H - 1);
+                pre[i] = ldg4(src + (size_t)yy * W * Ci + max(f_g[i], 0));
             }
         }
     }
@@ -101,17 +110,14 @@ struct ConvTile {
                 for (int k = 0; k < 4; ++k) in_s[u8off[i][k]] = ok ? (float)((prew[i] >> (8 * k)) & 255u) * (1.0f / 255.0f) : 0.f;
             }
         } else {
-            const int c4 = Ci >> 2, total = (R + 2) * PW * c4;
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
-                const int e = tid + i * FQL_THREADS;
-                if (e >= total) continue;
-                const int cc = e % c4, px = e / c4;
-                const int xx = px % PW - 1, yy = y0 + px / PW - 1;
+                if (f_rr[i] < 0) continue;
+                const int yy = y0 + f_rr[i] - 1;
                 f32x4 v = pre[i];
                 if (in_mode == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                if (xx < 0 || xx >= W || yy < 0 || yy >= H) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4*>(in_s + px * CS + 4 * cc) = v;
+                if (f_g[i] < 0 || yy < 0 || yy >= H) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(in_s + f_lds[i]) = v;
             }
         }
     }
@@ -133,8 +139,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
     ConvTile T;
     T.in = P.in; T.in_s = in_s; T.H = H; T.W = W; T.Ci = Ci; T.Ci_real = P.Ci_real; T.R = R; T.in_mode = P.in_mode; T.CS = CS; T.PW = PW; T.tid = tid;
     if constexpr (PIPE) {
-        T.fetch(wg / blocks_per_img, (wg % blocks_per_img) * R);
         T.init();
+        T.fetch(wg / blocks_per_img, (wg % blocks_per_img) * R);
     }
 
     // ---- weights -> LDS ([out channel][k]); staged once, the workgroup then walks its share of the row blocks
@@ -302,11 +308,11 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradArgs& P, float* l
         }
     };
     const int wg = (int)blockIdx.x - P.tile0, nwg = P.nwg;
+    T.init();
     if (wg < P.nblocks) {
         T.fetch(wg / blocks_per_img, (wg % blocks_per_img) * R);
         fetch_d(wg / blocks_per_img, (wg % blocks_per_img) * R);
     }
-    T.init();
     f32x4 acc[NU][CO_TILES];
 #pragma unroll
     for (int k = 0; k < NU; ++k)
