@@ -25,17 +25,25 @@ import numpy as np  # noqa: E402
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (matrix), v_mfma_f32_16x16x4_f32
 
 
-def cpu_baseline(cfg, od, ad, B, budget_s=20.0):
-    """Times the torch-CPU restatement of the reference update (oracle/, "port") on this host."""
+def cpu_baseline(cfg, od, ad, B, budget_s=20.0, img=None):
+    """Times the torch-CPU restatement of the reference update (oracle/, "port") on this host.  img = (H, W, C): visual agent."""
     import torch
     from oracle import fql_oracle as O
     from oracle.fql_oracle_torch import TorchFQL
     cores = torch.get_num_threads()
-    params = O.init_params(0, od, ad, dict(cfg))
+    params = O.init_params(0, img if img else od, ad, dict(cfg))
     ref = TorchFQL(params, dict(cfg), torch.float32)
-    ds = O.make_synthetic_dataset(8192, od, ad, seed=0)
     rng = np.random.default_rng(1)
-    batches = [(O.sample_batch(ds, rng.integers(0, 8192, size=B)), O.make_noise(B, ad, 10 + i)) for i in range(4)]
+    if img:
+        def vb():
+            return {'observations': rng.integers(0, 256, size=(B,) + tuple(img), dtype=np.uint8),
+                    'next_observations': rng.integers(0, 256, size=(B,) + tuple(img), dtype=np.uint8),
+                    'actions': rng.uniform(-1, 1, size=(B, ad)).astype(np.float32),
+                    'rewards': -np.ones(B, np.float32), 'masks': np.ones(B, np.float32)}
+        batches = [(vb(), O.make_noise(B, ad, 10 + i)) for i in range(2)] * 2
+    else:
+        ds = O.make_synthetic_dataset(8192, od, ad, seed=0)
+        batches = [(O.sample_batch(ds, rng.integers(0, 8192, size=B)), O.make_noise(B, ad, 10 + i)) for i in range(4)]
     ref.update(*batches[0])  # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
@@ -163,8 +171,8 @@ def main():
                          'kernel_launches_per_update': st['launches_per_update']},
             'last_info': {k: round(v, 5) for k, v in info.items()},
         }
-        if world == 1 and not args.no_cpu_baseline and not visual:
-            out['cpu_baseline'] = cpu_baseline(cfg, od, ad, B)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(cfg, od, ad, B, img=(64, 64, 9) if visual else None)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

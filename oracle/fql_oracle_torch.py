@@ -56,12 +56,43 @@ def _mlp(net, x, member=None):
     return x
 
 
+def _encode(mod, obs):
+    """utils/encoders.py:83-100 (ImpalaEncoder) when the module has an encoder, identity otherwise.  Written with
+    torch.nn.functional ops, independently of oracle/encoder_oracle.py's im2col restatement."""
+    if 'encoder' not in mod:
+        return obs
+    F = torch.nn.functional
+    p = mod['encoder']
+    x = (obs / 255.0).permute(0, 3, 1, 2)
+
+    def conv(x, c):   # flax Conv, SAME, HWIO kernel -> torch OIHW
+        return F.conv2d(x, c['kernel'].permute(3, 2, 0, 1), c['bias'], padding=1)
+
+    ns = sum(1 for k in p if k.startswith('stack_blocks_'))
+    for si in range(ns):
+        st = p[f'stack_blocks_{si}']
+        x = conv(x, st['Conv_0'])
+        x = F.max_pool2d(F.pad(x, (0, 1, 0, 1), value=float('-inf')), 3, 2)   # SAME: the pad sits at the end
+        for b in range((len(st) - 1) // 2):
+            inp = x
+            x = conv(F.relu(x), st[f'Conv_{1 + 2 * b}'])
+            x = conv(F.relu(x), st[f'Conv_{2 + 2 * b}'])
+            x = x + inp
+    x = F.relu(x).permute(0, 2, 3, 1).reshape(x.shape[0], -1)
+    for i in range(len(p['MLP_0'])):
+        d = p['MLP_0'][f'Dense_{i}']
+        x = _gelu(x @ d['kernel'] + d['bias'])
+    return x
+
+
 def _value(mod, obs, act):
-    x = torch.cat([obs, act], -1)
+    x = torch.cat([_encode(mod, obs), act], -1)
     return torch.stack([_mlp(mod['value_net'], x, e).squeeze(-1) for e in range(2)], 0)
 
 
-def _vf(mod, obs, act, t=None):
+def _vf(mod, obs, act, t=None, encoded=False):
+    if not encoded:
+        obs = _encode(mod, obs)
     return _mlp(mod['mlp'], torch.cat([obs, act] if t is None else [obs, act, t], -1))
 
 
@@ -105,9 +136,10 @@ class TorchFQL:
         bc = ((pred - vel) ** 2).mean()
         a = z
         n = int(cfg['flow_steps'])
+        eobs = _encode(stored['modules_actor_bc_flow'], obs)   # agents/fql.py:162-163: encoded once, is_encoded=True
         for i in range(n):  # agents/fql.py:166-169
             ti = torch.full((obs.shape[0], 1), i / n, dtype=self.dtype)
-            a = a + _vf(stored['modules_actor_bc_flow'], obs, a, ti) / n
+            a = a + _vf(stored['modules_actor_bc_flow'], eobs, a, ti, encoded=True) / n
         tgt = torch.clamp(a, -1, 1)
         aa = _vf(gp['modules_actor_onestep_flow'], obs, z)
         distill = ((aa - tgt) ** 2).mean()

@@ -158,3 +158,25 @@ def test_visual_update_runs_and_moves_every_trainable_leaf():
     for k in before:
         if k.endswith('kernel'):
             assert not np.array_equal(before[k], after[k]), k
+
+
+def test_visual_numpy_oracle_equals_torch_autograd_restatement():
+    """The hand-derived visual backward (fql_oracle + encoder_oracle) against torch.autograd over F.conv2d / F.max_pool2d."""
+    from oracle.fql_oracle_torch import TorchFQL
+    O, cfg, agent, batch, noise = make_visual_problem(B=4, hw=16, c=3, enc='impala_debug')
+    tref = TorchFQL(agent.params, cfg, torch.float64)
+    loss, info, grads = agent.grads(batch, noise)
+    tl, tinfo, tg = tref.grads(batch, noise)
+    assert abs(float(tl) - loss) <= 1e-10 * abs(loss)
+    for k, v in tinfo.items():
+        assert abs(float(v.detach()) - info[k]) <= 1e-9 * (1 + abs(info[k])), k
+    gl = dict(O.tree_leaves_with_path(grads))
+    for path, g in O.tree_leaves_with_path(tg):
+        np.testing.assert_allclose(g.numpy(), gl[path], rtol=1e-8, atol=1e-11, err_msg=path)
+    # three updates stay together (Adam, Polyak incl. the encoder leaves)
+    for s in range(3):
+        nz = O.make_noise(4, 4, 30 + s)
+        _, ia = agent.update(batch, nz)
+        _, ib = tref.update(batch, nz)
+        for k in ia:
+            assert abs(ia[k] - ib[k]) <= 1e-8 * (1 + abs(ia[k])), k
