@@ -701,7 +701,8 @@ struct fql_engine {
         t.flags = GF_BIAS | GF_GELU | GF_SAVE_Z;
         op.reads = {t.A, t.B};
         op.writes = {t.C, t.Zout};
-        if (want64(t.M, t.N, t.K, t.flags)) op.type = OP_GEMM64;
+        // (the LDS-tiled kernel whichever lane this pass is on: K = flat does not fit the 16-row kernel's A tile)
+        if (t.M % 64 == 0 && t.N % 64 == 0 && t.K % 64 == 0) op.type = OP_GEMM64;
         else if (t.K > 1024) invalid("encoder Dense with %d inputs needs a batch that is a multiple of 64", t.K);
         push(pr, op);
     }
@@ -768,7 +769,7 @@ struct fql_engine {
             t.Zprev = xfinal + (size_t)img0 * en.flat;
             op.reads = {b.dz, t.B, xfinal};
             op.writes = {b.dA};
-            if (want64(t.M, t.N, t.K, t.flags)) op.type = OP_GEMM64;
+            if (t.M % 64 == 0 && t.N % 64 == 0 && t.K % 64 == 0) op.type = OP_GEMM64;
             push(pr, op);
         }
         (void)lst;
@@ -1652,7 +1653,8 @@ struct fql_engine {
         // Lane 0 carries the critical path (prep -> Euler chain -> actor loss -> one-step backward); the rest of
         // the step runs beside it on lane 1 (a second graph branch) and only meets it at the actor loss.
         if (visual) {   // every module encodes the batch images first (agents/fql.py:196-202); the encodings feed prep
-            place("enc", 1, true);
+            // (data-parallel split program: on lane 0, so that lane 1 depends on lane 0 only through the prep kernel)
+            place("enc", split_build ? 0 : 1, true);
             emit_encoder_forward(pr, eb_os);   // [obs ; next_obs]: sample_actions(next_obs) fql.py:25, onestep(obs) fql.py:65,82
             emit_encoder_forward(pr, eb_c);    // critic(obs, .) fql.py:36,70 (same stored encoder and images: one pass)
             emit_encoder_forward(pr, eb_t);    // target_critic(next_obs, .) fql.py:28
@@ -1768,7 +1770,7 @@ struct fql_engine {
         }
         if (with_grads) emit_backward(pr, p_os_bwd, B, B, true, visual);
         if (with_grads && visual) {   // the obs half of the [obs ; next_obs] pass
-            place("enc", 1, true);
+            place("enc", split_build ? 0 : 1, true);
             emit_encoder_backward(pr, eb_os, 0, B, p_os_bwd.dx0, nullptr, nets[NET_OS].in_p());
             if (enc_align) {   // all three encoder backward passes level-aligned with the last one: their ops share launches
                 emit_encoder_backward(pr, eb_c, 0, B, p_c1[0].dx0, p_c1[1].dx0, nets[NET_C0].in_p(), p_os_bwd.dx0);

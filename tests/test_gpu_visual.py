@@ -231,3 +231,32 @@ def test_visual_full_size_is_deterministic_and_consistent():
         np.testing.assert_array_equal(pa[k], pb[k], err_msg=k)
     moved = [k for k in pa if not k.startswith('modules_target') and k.endswith('kernel')]
     assert all(np.abs(pa[k]).sum() > 0 for k in moved)
+
+
+def test_visual_split_lane_update_matches_plain_update():
+    """The data-parallel form for visual agents: encoders on lane 0 in front of prep, critic/bc encoder gradients in bucket 0,
+    the one-step encoder's in bucket 1; fql_update_begin_split + fql_update_end == fql_update."""
+    import torch
+    import fql_amd
+    cfg, batch, _ = make_visual(B=64, seed=13)
+    a = fql_amd.FQLAgent.create(0, batch['observations'][:1], batch['actions'][:1], cfg)
+    b = fql_amd.FQLAgent.create(0, batch['observations'][:1], batch['actions'][:1], cfg)
+    b.set_params(a.get_params())
+    buckets = b.grad_buckets()
+    ptr, n = b.grad_buffer()
+    assert buckets is not None and buckets[0][0] == 0 and buckets[0][1] == buckets[1][0] and buckets[1][0] + buckets[1][1] == n
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+    for step in range(2):
+        nz = O.make_noise(64, 4, 60 + step)
+        a.update(batch, noise=nz)
+        torch.cuda.synchronize()
+        b.update_begin_split(s0.cuda_stream, s1.cuda_stream, batch=batch, noise=nz)
+        s0.wait_stream(s1)
+        b.update_end(stream=s0.cuda_stream)
+        torch.cuda.synchronize()
+        ia, ib = a.read_info(), b.read_info()
+        for k in ia:
+            assert abs(ia[k] - ib[k]) <= 1e-6 * max(1.0, abs(ia[k])), (step, k, ia[k], ib[k])
+    pa, pb = leaf_dict(a.get_params()), leaf_dict(b.get_params())
+    for p in pa:
+        np.testing.assert_allclose(pb[p], pa[p], rtol=0, atol=1e-7, err_msg=p)
