@@ -68,6 +68,9 @@ def main():
     ap.add_argument('--workload', choices=['state', 'visual'], default='state',
                     help="state = BASELINE.json configs[1] (the headline metric); visual = configs[4] (impala_small, 64x64x9 uint8)")
     ap.add_argument('--frames', type=int, default=20_000, help='frames in the synthetic visual dataset')
+    ap.add_argument('--obs-dim', type=int, default=29, help='state workload: observation width (configs[2] uses 40)')
+    ap.add_argument('--act-dim', type=int, default=8, help='state workload: action width (configs[2] uses 4)')
+    ap.add_argument('--alpha', type=float, default=None, help='BC coefficient (default 10 for the state workload, 300 visual)')
     args = ap.parse_args()
 
     import torch
@@ -88,7 +91,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
-    od, ad, B = 29, 8, args.batch
+    od, ad, B = args.obs_dim, args.act_dim, args.batch
     cfg = fql_amd.get_config()
     visual = args.workload == 'visual'
     if visual:
@@ -107,7 +110,7 @@ def main():
         agent = fql_amd.FQLAgent.create(rank, np.zeros((1, 64, 64, 9), np.uint8), ds['actions'][:1], cfg)
         agent.upload_dataset(ds, frame_stack=3, p_aug=0.5)
     else:
-        cfg.update(alpha=10.0, batch_size=B)
+        cfg.update(alpha=10.0 if args.alpha is None else args.alpha, batch_size=B)
         ds = O.make_synthetic_dataset(args.rows, od, ad, seed=0)
         agent = fql_amd.FQLAgent.create(rank, ds['observations'][:1], ds['actions'][:1], cfg)
         agent.upload_dataset(ds)
@@ -160,8 +163,11 @@ def main():
             'config': {'workload': ('visual-cube-shaped synthetic replay (uint8 64x64x9 = 3 stacked frames, act=5), impala_small encoders, '
                                     f'batch={B}/GPU, hidden=512x4, flow_steps=10, alpha=300, p_aug=0.5, {args.frames} device-resident frames '
                                     '(BASELINE.json configs[4])') if visual else
-                                   ('antmaze-large-shaped synthetic replay (obs=29, act=8), batch=256/GPU, hidden=512x4, '
-                                    'flow_steps=10, alpha=10, 1M device-resident transitions (BASELINE.json configs[1])'),
+                                   (f'antmaze-large-shaped synthetic replay (obs={od}, act={ad}), batch={B}/GPU, hidden=512x4, '
+                                    f'flow_steps=10, alpha={cfg["alpha"]:g}, 1M device-resident transitions (BASELINE.json configs[1])'
+                                    if (od, ad, B) == (29, 8, 256) else
+                                    f'synthetic replay (obs={od}, act={ad}), batch={B}/GPU, hidden=512x4, flow_steps=10, '
+                                    f'alpha={cfg["alpha"]:g}, device-resident transitions (BASELINE.json configs[2] shape when 40/4/1024)'),
                        'parallelism': f'dp{world}', 'samples_per_s': round(steps_per_s * world * B, 1)},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), 'traffic': None,

@@ -1186,14 +1186,19 @@ struct fql_engine {
                     for (const Op* o : selw) launch_of[o - pr.ops.data()] = li;
                     for (const Op* o : sell) launch_of[o - pr.ops.data()] = li;
                     for (const Op* o : selm) launch_of[o - pr.ops.data()] = li;
-                    static const int ri = getenv("FQL_G64_RI") ? atoi(getenv("FQL_G64_RI")) : 1;
+                    // 32 x 64 tiles while a level is a latency chain (B = 256: 1.5 workgroups per CU), 64 x 64 once a task alone
+                    // brings >= 128 of them (M >= 1024: +2 % at B = 1024)
+                    static const int ri_env = getenv("FQL_G64_RI") ? atoi(getenv("FQL_G64_RI")) : 0;
+                    int ri = 1;
                     int tile = 0;
                     std::vector<GemmTask> tg;
                     for (const Op* o : sel) {
                         GemmTask t = o->gemm;
-                        t.wk = 1; t.tmt = ri;
+                        const int ri_t = ri_env ? ri_env : (t.M >= 1024 && t.M % 64 == 0 ? 2 : 1);
+                        ri = std::max(ri, ri_t);
+                        t.wk = 1; t.tmt = ri_t;
                         t.ntn = t.N / 64; t.tile0 = tile;
-                        tile += (t.M / (32 * ri)) * t.ntn;
+                        tile += (t.M / (32 * ri_t)) * t.ntn;
                         tg.push_back(t);
                     }
                     L.tile_w = tile;
@@ -1332,7 +1337,8 @@ struct fql_engine {
                     std::vector<GemmTask> tb;
                     for (const Op* o : sel) {
                         GemmTask t = o->gemm;
-                        static const int ri = getenv("FQL_G64_RI") ? atoi(getenv("FQL_G64_RI")) : 1;
+                        static const int ri_env = getenv("FQL_G64_RI") ? atoi(getenv("FQL_G64_RI")) : 0;
+                        const int ri = ri_env ? ri_env : (t.M >= 1024 && t.M % 64 == 0 ? 2 : 1);
                         t.wk = 1; t.tmt = ri;  // row tiles per wave: workgroup tile (32 ri) x 64
                         t.ntn = t.N / 64;
                         t.tile0 = tile;
@@ -1926,8 +1932,11 @@ struct fql_engine {
                 // teams: as many as fit one workgroup per CU; each takes B / 16 / teams row tiles
                 pec_teams = std::min(B / 16, num_cus / (H / 32));
                 while (pec_teams > 1 && (B / 16) % pec_teams) --pec_teams;
-                use_pec = fused_euler && same && getenv("FQL_PEC") != nullptr && pec_teams >= 1 && B / 16 / pec_teams <= PEC_MAX_TILES &&
-                          cfg.flow_steps <= 20;
+                // default: on when every team has >= 4 row tiles to walk per phase (B >= 1024: +5 %); at B = 256 / 512 the chain
+                // is shorter but the update is not.  FQL_PEC=1 / 0 forces it on / off.
+                const int pec_tiles = pec_teams >= 1 ? B / 16 / pec_teams : 0;
+                const bool pec_want = getenv("FQL_PEC") ? atoi(getenv("FQL_PEC")) != 0 : pec_tiles >= 4;
+                use_pec = fused_euler && same && pec_want && pec_teams >= 1 && pec_tiles <= PEC_MAX_TILES && cfg.flow_steps <= 20;
                 if (use_pec) {
                     pec_epoch = (unsigned*)dalloc(W, (size_t)pec_teams + 1);
                     for (int i = 0; i < 2; ++i) pec_g[i] = (fql_u64*)dalloc(W, (size_t)B * H * 2);

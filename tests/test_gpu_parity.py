@@ -187,3 +187,21 @@ def test_batch_size_switch_keeps_state():
         np.testing.assert_array_equal(a, before[p], err_msg=p)
     agent.update(batch, noise=noise)                                                  # and back to 64
     assert agent.get_opt_state()['count'] == 1
+
+
+def test_config3_shape_b1024_matches_oracle():
+    """BASELINE configs[2] shape (obs 40, act 4, alpha 300, B 1024, hidden 512x4): at this size the engine's defaults switch
+    to 64x64 side tiles and the persistent Euler chain with 4 row tiles per team; one update against the fp64 oracle."""
+    import fql_amd
+    od, ad, B = 40, 4, 1024
+    cfg, ds, batch, noise = make_problem(od, ad, B, (512, 512, 512, 512), seed=31, alpha=300.0)
+    agent = fql_amd.FQLAgent.create(0, batch['observations'][:1], batch['actions'][:1], cfg)
+    params = randomize_params(agent.get_params(), seed=6, scale=0.05)
+    agent.set_params(params)
+    ref = O.OracleFQL(params, dict(cfg), od, ad, np.float64)
+    for s in range(2):
+        nz = O.make_noise(B, ad, 70 + s)
+        _, ig = agent.update(batch, noise=nz)
+        _, ir = ref.update(batch, nz)
+        assert_info_close(ig, ir, rtol=1e-4, atol=1e-5)
+    assert agent.stats()['launches_per_update'] < 50     # the Euler chain is one launch here
