@@ -34,3 +34,35 @@ def test_replay_buffer_ring_semantics_match_reference():
     assert (rb.size, rb.pointer) == (0, 0)
     empty = ReplayBuffer.create({k: v[0] for k, v in init.items()}, size=4)
     assert empty.max_size == 4 and empty.size == 0 and empty['observations'].shape == (4, 5)
+
+
+def test_frame_stack_and_augment_follow_the_reference():
+    """utils/datasets.py:73-112 on the host mirror, against the oracle's restatement (oracle/encoder_oracle.py)."""
+    from oracle import encoder_oracle as E
+    from fql_amd.datasets import Dataset
+    rng = np.random.default_rng(3)
+    n = 60
+    frames = rng.integers(0, 256, size=(n, 8, 8, 3), dtype=np.uint8)
+    nxt = rng.integers(0, 256, size=(n, 8, 8, 3), dtype=np.uint8)
+    term = np.zeros(n, np.float32); term[[9, 29, 59]] = 1
+    ds = Dataset.create(observations=frames, next_observations=nxt, terminals=term, masks=1 - term,
+                        actions=rng.uniform(-1, 1, size=(n, 2)).astype(np.float32), rewards=np.zeros(n, np.float32))
+    np.testing.assert_array_equal(ds.initial_locs, [0, 10, 30])            # the last terminal starts no episode
+    ds.frame_stack = 3
+    idxs = np.array([0, 1, 10, 11, 12, 30, 59])
+    b = ds.sample(len(idxs), idxs=idxs)
+    obs, nobs = E.stack_frames(frames, nxt, term, idxs, 3)
+    np.testing.assert_array_equal(b['observations'], obs)
+    np.testing.assert_array_equal(b['next_observations'], nobs)
+    assert b['observations'].shape == (7, 8, 8, 9)
+    np.testing.assert_array_equal(b['observations'][2, ..., 0:3], frames[10])   # clamped to the episode start
+    np.testing.assert_array_equal(b['observations'][2, ..., 6:9], frames[10])
+    crops = rng.integers(0, 7, size=(7, 2))
+    want_o, want_n = E.random_crop_batch(obs, crops), E.random_crop_batch(nobs, crops)
+    ds.augment(b, ['observations', 'next_observations'], crop_froms=crops)
+    np.testing.assert_array_equal(b['observations'], want_o)
+    np.testing.assert_array_equal(b['next_observations'], want_n)
+    ds.p_aug = 1.0
+    np.random.seed(0)
+    b2 = ds.sample(5)
+    assert b2['observations'].shape == (5, 8, 8, 9) and b2['observations'].dtype == np.uint8

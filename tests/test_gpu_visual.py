@@ -260,3 +260,27 @@ def test_visual_split_lane_update_matches_plain_update():
     pa, pb = leaf_dict(a.get_params()), leaf_dict(b.get_params())
     for p in pa:
         np.testing.assert_allclose(pb[p], pa[p], rtol=0, atol=1e-7, err_msg=p)
+
+
+def test_dataset_mirror_attach_uploads_frames():
+    """fql_amd.datasets.Dataset with frame_stack set (main.py:120): attach() -> device gather == host sample() + update()."""
+    import fql_amd
+    from fql_amd.datasets import Dataset
+    B, hw, ad, fs = 32, 32, 4, 3
+    cfg, _, _ = make_visual(B=B, hw=hw, c=3 * fs, ad=ad)
+    rng = np.random.default_rng(17)
+    n = 150
+    term = (rng.random(n) < 0.04).astype(np.float32); term[-1] = 1
+    ds = Dataset.create(observations=rng.integers(0, 256, size=(n, hw, hw, 3), dtype=np.uint8),
+                        next_observations=rng.integers(0, 256, size=(n, hw, hw, 3), dtype=np.uint8), terminals=term, masks=1 - term,
+                        actions=rng.uniform(-1, 1, size=(n, ad)).astype(np.float32), rewards=-np.ones(n, np.float32))
+    ds.frame_stack = fs
+    ex = np.zeros((1, hw, hw, 3 * fs), np.uint8)
+    a = fql_amd.FQLAgent.create(5, ex, ds['actions'][:1], cfg)
+    b = fql_amd.FQLAgent.create(5, ex, ds['actions'][:1], cfg)
+    ds.attach(a)
+    idxs = rng.integers(0, n, size=B)
+    nz = O.make_noise(B, ad, 18)
+    _, ia = a.update_from_dataset(B, idxs=idxs, noise=nz, want_info=True)
+    _, ib = b.update(ds.sample(B, idxs=idxs), noise=nz)
+    assert ia == ib
