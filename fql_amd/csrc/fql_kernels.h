@@ -1581,6 +1581,23 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_euler_persistent_kernel(const
     };
     // a 16 x H tile: thread t sweeps granules t + 256 k (row k / KPR) until all carry `tag`, then stages them in LDS
     auto gather_tile = [&](const fql_u64* src, int row0, unsigned tag) {
+#ifndef FQL_PEC_NO_SENTINEL
+        // hint poll (guide: one idle wave polls, with s_sleep): lanes 0..T-1 of wave 0 watch the LAST granule each member
+        // stores (row 15, last column of its slice) before anybody sweeps; the sweep below still checks every tag, so this
+        // only keeps 64 KB sweeps of a tile that is not there yet off the CU's memory pipe while other kernels share it
+        // (with >= 4 row tiles per team the tile was published a whole round ago and the hint only costs a barrier: skipped)
+        if (ntile < 4 && wave == 0) {
+            const fql_u64* sp = src + (size_t)(row0 + 15) * H + min(lane, T - 1) * 32 + 31;
+            fql_u64 t1 = 0;
+            for (;;) {
+                const bool ok = lane >= T || (unsigned)(ld_granule(sp) >> 32) == tag;
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(8);
+                if (pec_spin_fail(t1, P.err)) break;
+            }
+        }
+        if (ntile < 4) __syncthreads();
+#endif
         const fql_u64* sb = src + (size_t)row0 * H + tid;
         asm volatile("" : "+v"(sb));
         constexpr int NG = 16 * KPR;
