@@ -1433,6 +1433,16 @@ struct fql_engine {
             for (int l = 1; l < FQL_LANES; ++l) if (pr.lane_used[l]) HIP_CHECK(hipStreamWaitEvent(ls[l], pr.ev_fork, 0));
         }
         static const int only_lane = getenv("FQL_ONLY_LANE") ? atoi(getenv("FQL_ONLY_LANE")) : -1;  // timing experiments
+        static const int blocker_us = getenv("FQL_BLOCKER") ? atoi(getenv("FQL_BLOCKER")) : 0;
+        if (blocker_us > 0 && par && pr.launches.size() > 20) {   // experiment: take `FQL_BLOCKER_N` CUs away for blocker_us
+            static const int nb = getenv("FQL_BLOCKER_N") ? atoi(getenv("FQL_BLOCKER_N")) : 128;
+            static bool attr = false;
+            const size_t lds = 115 * 1024;
+            if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)fql_blocker_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+            HIP_CHECK(hipStreamWaitEvent(ls[3], pr.ev_fork, 0));
+            hipLaunchKernelGGL(fql_blocker_kernel, dim3(nb), dim3(FQL_THREADS), lds, ls[3], (unsigned long long)blocker_us * 100ull);
+            pr.lane_used[3] = true;
+        }
         for (Launch& L : pr.launches) {
             if (only_lane >= 0 && pr.two_lanes && L.lane != only_lane) continue;
             static const int skip_lane = getenv("FQL_SKIP_LANE") ? atoi(getenv("FQL_SKIP_LANE")) : -1;
