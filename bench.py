@@ -97,7 +97,6 @@ def main():
     if visual:
         # BASELINE.json configs[4] / SURVEY.md 8d "Config 5": uint8 frames, frame_stack 3 -> [64, 64, 9], impala_small encoders,
         # alpha 300, p_aug 0.5; act_dim is a runtime parameter (cube-single: 5)
-        import numpy as np
         ad = 5
         n = args.rows = args.frames
         rng = np.random.default_rng(0)
@@ -179,6 +178,17 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, od, ad, B, img=(64, 64, 9) if visual else None)
+            if not visual:
+                # "loss delta vs the reference" (BASELINE.json metric), against the CPU restatement: one total_loss on the
+                # engine's CURRENT parameters and a fixed synthetic batch with explicit noise, fp64 oracle (checker only)
+                pb = O.sample_batch(ds, np.random.default_rng(3).integers(0, args.rows, size=B))
+                pn = O.make_noise(B, ad, 4)
+                ref = O.OracleFQL(agent.get_params(), {k: v for k, v in dict(cfg).items() if k != 'rng'}, od, ad, np.float64)
+                lg, ig = agent.total_loss(pb, None, noise=pn)
+                lr, ir = ref.total_loss(pb, pn)
+                out['cpu_baseline']['loss_delta'] = {'total_loss_gpu': round(float(lg), 6), 'total_loss_oracle': round(float(lr), 6),
+                                                     'abs_delta': float(abs(lg - lr)),
+                                                     'max_abs_delta_info': float(max(abs(ig[k] - ir[k]) for k in ir))}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
