@@ -105,11 +105,11 @@ class FQLAgent:
         lib.fql_default_config(C.byref(c))
         if cfg.get('encoder') is not None:
             # agents/fql.py:196-202: one encoder per module in front of the MLPs; observations are uint8 images [H, W, C]
-            if cfg['encoder'] != 'impala_small':
-                raise NotImplementedError(f"encoder {cfg['encoder']!r}: only 'impala_small' (utils/encoders.py:106) is built")
+            if cfg['encoder'] not in ('impala_small', 'impala'):
+                raise NotImplementedError(f"encoder {cfg['encoder']!r}: 'impala_small' and 'impala' (utils/encoders.py:104,106) are built")
             if len(ob_dims) != 3:
                 raise ValueError(f'image observations [H, W, C] expected with an encoder, got ob_dims={ob_dims}')
-            c.encoder, c.img_h, c.img_w, c.img_c = 1, ob_dims[0], ob_dims[1], ob_dims[2]
+            c.encoder, c.img_h, c.img_w, c.img_c = (1 if cfg['encoder'] == 'impala_small' else 2), ob_dims[0], ob_dims[1], ob_dims[2]
             c.obs_dim = 1
         else:
             if len(ob_dims) != 1:

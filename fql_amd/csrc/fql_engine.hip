@@ -335,7 +335,8 @@ struct fql_engine {
             for (int s = 0; s < 3; ++s) {
                 EncStack st;
                 st.H = H; st.W = W;
-                for (int j = 0; j < 3; ++j) {
+                const int nconv = 1 + 2 * (cfg.encoder == 2 ? 2 : 1);   // impala: num_blocks 2, impala_small: 1 (utils/encoders.py:67,106)
+                for (int j = 0; j < nconv; ++j) {
                     ConvL c{};
                     c.cin = cin; c.cout = sizes[s];
                     c.w = off; off += (size_t)9 * c.cin * c.cout;
@@ -468,7 +469,7 @@ struct fql_engine {
             }
         }
         n_train_leaves = tid;
-        if (n_train_leaves > 128) invalid("too many trainable leaves (%d)", n_train_leaves);
+        if (n_train_leaves > 256) invalid("too many trainable leaves (%d)", n_train_leaves);
         // Adam chunks: contiguous pieces of one leaf, <= 4096 elements
         std::vector<AdamChunk> ch;
         for (const Leaf& lf : leaves) {
@@ -2283,7 +2284,7 @@ int fql_create(const fql_config* cfg, uint64_t seed, fql_handle* out) {
         h->cfg = *cfg;
         h->seed = seed;
         if (cfg->encoder != 0) {   // visual agent (agents/fql.py:196-202): the MLPs see the 512-wide encoding instead of obs
-            if (cfg->encoder != 1) invalid("encoder %d not available (0 = none, 1 = impala_small)", cfg->encoder);
+            if (cfg->encoder != 1 && cfg->encoder != 2) invalid("encoder %d not available (0 = none, 1 = impala_small, 2 = impala)", cfg->encoder);
             if (cfg->img_h <= 0 || cfg->img_w <= 0 || cfg->img_h % 32 || cfg->img_w % 32 || cfg->img_w > 128 || cfg->img_c <= 0 || cfg->img_c > 16)
                 invalid("image shape must be [H, W, C] with H, W multiples of 32 (W <= 128) and C <= 16 (got %d, %d, %d)", cfg->img_h,
                         cfg->img_w, cfg->img_c);

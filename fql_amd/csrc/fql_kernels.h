@@ -1027,7 +1027,7 @@ struct DevState {
     float info[16];      // the 13 info scalars (+ scratch)
     float gmax_bits_pad; // unused
     int gmax, gmin;      // ordered-int encodings for atomicMax/Min
-    float leaf_sumsq[128];
+    float leaf_sumsq[256];
 };
 
 struct SrcDesc {  // where the batch comes from; rewritten by the host only when it changes
@@ -1380,7 +1380,7 @@ struct FinalizeArgs {
 // contribute zeros, which bound grad/max >= 0 >= grad/min (F5).  Also advances optax count / TrainState.step / RNG step.
 __global__ __launch_bounds__(FQL_THREADS) void fql_finalize_kernel(FinalizeArgs A) {
     __shared__ float sh[4];
-    __shared__ float leafn[128];
+    __shared__ float leafn[256];
     DevState* st = A.st;
     if (!A.do_grad_stats) return;
     float mx = -INFINITY, mn = INFINITY;

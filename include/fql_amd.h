@@ -66,7 +66,7 @@ typedef struct fql_config {
     int32_t normalize_q_loss;                /* False                                              */
     int32_t batch_size;                      /* 256: rows per update on this device (multiple of 16) */
     int32_t precision;                       /* 0 = fp32 MFMA (exact fp32 fma chains)              */
-    int32_t encoder;                         /* 0 = state observations; 1 = impala_small (utils/encoders.py:106): obs_dim is
+    int32_t encoder;                         /* 0 = state observations; 1 = impala_small, 2 = impala (utils/encoders.py:104,106; stacks 16/32/32, 1 or 2 blocks): obs_dim is
                                                 ignored, observations are uint8 [B, img_h, img_w, img_c] (agents/fql.py:196-202) */
     int32_t img_h, img_w, img_c;             /* image shape after frame stacking (e.g. 64, 64, 9); img_h, img_w multiples of 8 */
     int32_t reserved[3];

@@ -284,3 +284,21 @@ def test_dataset_mirror_attach_uploads_frames():
     _, ia = a.update_from_dataset(B, idxs=idxs, noise=nz, want_info=True)
     _, ib = b.update(ds.sample(B, idxs=idxs), noise=nz)
     assert ia == ib
+
+
+def test_impala_two_blocks_per_stack_matches_oracle():
+    """encoder='impala' (utils/encoders.py:104: num_blocks 2): 5 convolutions per stack, same kernels."""
+    import fql_amd
+    cfg, batch, _ = make_visual(seed=15, encoder='impala')
+    agent = fql_amd.FQLAgent.create(0, batch['observations'][:1], batch['actions'][:1], cfg)
+    params = randomize_params(agent.get_params(), seed=16, scale=0.05)
+    agent.set_params(params)
+    assert leaf_dict(params)['modules_critic/encoder/stack_blocks_2/Conv_4/kernel'].shape == (3, 3, 32, 32)
+    ref = O.OracleFQL(params, dict(cfg), (32, 32, 3), 4, np.float64)
+    obs, z = batch['observations'][:8], O.make_noise(32, 4, 90)['z'][:8]
+    np.testing.assert_allclose(agent.sample_actions(obs, noises=z), ref.sample_actions(obs, z), atol=1e-5)
+    for s in range(2):
+        nz = O.make_noise(32, 4, 80 + s)
+        _, ig = agent.update(batch, noise=nz)
+        _, ir = ref.update(batch, nz)
+        assert_info_close(ig, ir, rtol=2e-4, atol=2e-5)
