@@ -40,6 +40,7 @@ enum : int {
     GF_A_EULER0 = 1 << 11,  // fused Euler step, part 1: A tile = GELU(C0 + a W0[act rows] + t W0[t row]) built in LDS
     GF_HEAD_PART = 1 << 12, // fused Euler step, part 3: epilogue multiplies the GELU tile into the action head (partials)
     GF_OS_SCATTER = 1 << 13, // one-step head on [next_obs; obs; obs] rows: also write clip(out) into the critic inputs
+    GF_A_LOSSACT = 1 << 17,  // A tile = d(actor loss)/d(one-step actions) built in the prologue (agents/fql.py:66-79): no loss kernel on the critical path
     GF_RELUGRAD = 1 << 14,   // epilogue: C = (Zprev > 0) ? acc : 0  (dgrad through the encoder's final ReLU, utils/encoders.py:92)
     GF_LN_PART = 1 << 10,   // gemm64 epilogue: per-row (sum, sum sq) of this 64-column tile -> aux[row][i1 tiles][2]
 };
@@ -423,6 +424,25 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
                     for (int i = 0; i < 4; ++i) lds[(4 * q + i) * S + 16 * ct + c] = gelu_f(cacc[t][i]);
                 }
             }
+        }
+    } else if (EUL && TMT == 1 && (flags & GF_A_LOSSACT)) {
+        // head dgrad of the one-step actor: dA[r][a] = alpha 2/(B act) (a_raw - target) + [ -1 < a_raw < 1 ] (dQ/da member 0 + 1)
+        // (agents/fql.py:66 distill, :69-72 clip mask on the Q path).  ea_in = a_raw, evp = target (ld i0), ew / ew4 = the
+        // critic members' input gradients (ld lda of THEIR pass = e_ntp, action block at column i1), f0 = alpha 2 / (B act).
+        issue_b();
+        for (int e = tid; e < 16 * K; e += FQL_THREADS) {
+            const int r = e / K, j = e - r * K;
+            float g = 0.f;
+            if (j < T.i2) {
+                const float ar = ldg(T.ea_in + (size_t)(row0 + r) * T.i0 + j);
+                g = T.f0 * (ar - ldg(T.evp + (size_t)(row0 + r) * T.i0 + j));
+                if (ar > -1.0f && ar < 1.0f) {
+                    const size_t o = (size_t)(row0 + r) * T.e_ntp + T.i1 + j;
+                    g += ldg(T.ew + o) + ldg(T.ew4 + o);
+                }
+                if (tn == 0 && T.ea_out) stg(T.ea_out + (size_t)(row0 + r) * T.i0 + j, g);   // the head's wgrad reads it
+            }
+            lds[r * S + j] = g;
         }
     } else {
 #pragma unroll
