@@ -521,6 +521,19 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
         __syncthreads();
     }
 
+    // epilogue operand of the dgrad forms (GELU' / ReLU mask of the stored pre-activation): fetched before the MFMA loop so its
+    // L2 round trip is not the last thing on the launch's critical path
+    float zpre[TMT][4];
+#pragma unroll
+    for (int rt = 0; rt < TMT; ++rt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) zpre[rt][i] = 0.f;
+    if (active && kp == 0 && (flags & (GF_GELUGRAD | GF_RELUGRAD))) {
+#pragma unroll
+        for (int rt = 0; rt < TMT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) zpre[rt][i] = ldg(T.Zprev + (size_t)(row0 + 16 * rt + 4 * q + i) * T.ldc + n0 + c);
+    }
     f32x4 acc[TMT];
 #pragma unroll
     for (int r = 0; r < TMT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -590,8 +603,8 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
         }
         if (flags & GF_SAVE_Z) stg(T.Zout + o, v);
         if (flags & GF_GELU) v = gelu_f(v);
-        if (flags & GF_GELUGRAD) v *= gelu_grad_f(ldg(T.Zprev + o));
-        if (flags & GF_RELUGRAD) v = (ldg(T.Zprev + o) > 0.f) ? v : 0.f;
+        if (flags & GF_GELUGRAD) v *= gelu_grad_f(zpre[rt][i]);
+        if (flags & GF_RELUGRAD) v = (zpre[rt][i] > 0.f) ? v : 0.f;
         if (flags & GF_CLIP_OUT) v = clip1(v);
         stg(T.C + o, v);
         if ((flags & GF_OS_SCATTER) && n < T.i2) {
