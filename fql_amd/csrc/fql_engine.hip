@@ -206,6 +206,7 @@ struct fql_engine {
     hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, stream4 = nullptr;
     bool allow64 = true;
     int emit_lane = 0;
+    std::vector<Op>* defer_wgrads = nullptr;   // when set, emit_backward collects weight-gradient ops here instead of emitting them in place
     std::string err;
 
     Net nets[NUM_NETS];
@@ -1041,7 +1042,8 @@ struct fql_engine {
                 static const bool wlane = getenv("FQL_WLANE") != nullptr;  // (a separate wgrad lane is worse than sharing launches)
                 if (wlane) emit_lane = 2;
                 else if (emit_lane == 0 && !split_build && getenv("FQL_NO_WSIDE") == nullptr) emit_lane = 1;
-                push(pr, op);
+                if (defer_wgrads) { op.lane = emit_lane; defer_wgrads->push_back(op); }
+                else push(pr, op);
                 emit_lane = keep;
             }
             if (l == 0 && !input_grad) break;
@@ -1719,6 +1721,12 @@ struct fql_engine {
             if (with_grads) { op.writes.push_back(p_c1[0].dz.back()); op.writes.push_back(p_c1[1].dz.back()); }
             push(pr, op);
         }
+        // The critic's weight gradients gate nothing but Adam: they are emitted after the Q-gradient chain, whose levels on lane 1
+        // then carry fewer tiles and finish earlier - and with them the one-step actor's backward tail (2127 -> 2170 updates/s;
+        // deferring the BC flow's too: 2161, the critic's whole backward chain: 2050).  FQL_LATE_WGRAD: 0 off, 1 both, 2 critic, 3 bc.
+        static const int late_wgrad = getenv("FQL_LATE_WGRAD") ? atoi(getenv("FQL_LATE_WGRAD")) : 2;
+        std::vector<Op> late_ops;
+        if ((late_wgrad == 1 || late_wgrad == 2) && with_grads && !split_build) defer_wgrads = &late_ops;
         if (with_grads)
             for (int e = 0; e < 2; ++e) emit_backward(pr, p_c1[e], 0, B, true, visual);
         // (not in the data-parallel split program: there lane 1 must finish bucket 0 without waiting for lane 0's tail)
@@ -1739,6 +1747,7 @@ struct fql_engine {
             if (with_grads) op.writes.push_back(p_bc.dz.back());
             push(pr, op);
         }
+        defer_wgrads = ((late_wgrad == 1 || late_wgrad == 3) && with_grads && !split_build) ? &late_ops : nullptr;
         if (with_grads) emit_backward(pr, p_bc, 0, B, true, visual);
         if (with_grads && visual && !enc_align) {
             place("enc", 1, true);
@@ -1760,8 +1769,14 @@ struct fql_engine {
             if (dyn_dq) { op.writes.push_back(p_c2[0].dz.back()); op.writes.push_back(p_c2[1].dz.back()); }
             push(pr, op);
         }
+        defer_wgrads = nullptr;
         if (with_grads)
             for (int e = 0; e < 2; ++e) emit_backward(pr, p_c2[e], 0, B, false, true, I_CR);  // in phase with the c1 chain
+        for (Op& w : late_ops) {   // the critic's and the BC flow's weight gradients only after the Q-gradient chain (they gate nothing)
+            w.reads.push_back(p_c2[0].dx0); w.reads.push_back(p_c2[1].dx0);
+            emit_lane = w.lane;
+            push(pr, w);
+        }
         // Euler chain through the BC flow (fql.py:155-171): flow_steps sequential forwards
         place("eu", 0, false);
         const int fs = cfg.flow_steps;
