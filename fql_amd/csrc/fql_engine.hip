@@ -1809,16 +1809,26 @@ struct fql_engine {
             emit_lane = keep;
         }
         if (with_grads) {
+            // The one-step actor's weight gradients gate the last Adam launch.  On lane 1 they would queue behind the deferred critic
+            // weight gradients and the other two Adam launches; emitted here as ONE launch on lane 0 behind the last dgrad they
+            // cost ~10 us of tail instead.  (FQL_OS_WGRAD_SIDE=1: the old placement.)
+            static const bool os_w_side = getenv("FQL_OS_WGRAD_SIDE") != nullptr;
+            std::vector<Op> os_w;
+            if (!os_w_side && !split_build) defer_wgrads = &os_w;
             const size_t first = pr.ops.size();
             emit_backward(pr, p_os_bwd, B, B, true, visual);
+            defer_wgrads = nullptr;
             if (fuse_la) {
                 // the head's wgrad (emitted first) reads dA, which the head dgrad (emitted right after it) now PRODUCES:
                 // swap them so the scheduler sees the write before the read, then turn the dgrad's A operand into the builder
                 float* da = p_os_bwd.dz.back();
-                if (first + 1 >= pr.ops.size() || pr.ops[first].type != OP_WGRAD || pr.ops[first].wgrad.dZ != da ||
-                    pr.ops[first + 1].type != OP_GEMM || pr.ops[first + 1].gemm.A != da)
-                    invalid("internal: unexpected one-step backward program shape");
-                std::swap(pr.ops[first], pr.ops[first + 1]);
+                size_t id = first;
+                while (id < pr.ops.size() && !(pr.ops[id].type == OP_GEMM && pr.ops[id].gemm.A == da)) ++id;
+                if (id >= pr.ops.size() || id > first + 1) invalid("internal: unexpected one-step backward program shape");
+                if (id == first + 1) {   // (when the wgrads are emitted in place; deferred ones follow the chain anyway)
+                    if (pr.ops[first].type != OP_WGRAD || pr.ops[first].wgrad.dZ != da) invalid("internal: unexpected one-step backward program shape");
+                    std::swap(pr.ops[first], pr.ops[first + 1]);
+                }
                 Op& d = pr.ops[first];
                 GemmTask& t = d.gemm;
                 t.flags |= GF_A_LOSSACT;
@@ -1829,6 +1839,11 @@ struct fql_engine {
                 d.reads.erase(std::remove(d.reads.begin(), d.reads.end(), (const void*)da), d.reads.end());
                 for (const void* r : {(const void*)p_os.out, (const void*)tgt, (const void*)p_c2[0].dx0, (const void*)p_c2[1].dx0}) d.reads.push_back(r);
                 d.writes.push_back(da);
+            }
+            for (Op& w : os_w) {
+                w.reads.push_back(p_os_bwd.dz[0]);   // after the last dgrad: all five in one launch
+                emit_lane = 0;
+                push(pr, w);
             }
         }
         if (with_grads && visual) {   // the obs half of the [obs ; next_obs] pass
