@@ -67,6 +67,9 @@ class DataParallelFQL:
         # overlapped mode: the engine enqueues lane 1 (critics, BC flow) and lane 0 (Euler chain, one-step actor) on two
         # streams; the lane-1 gradient bucket (3/4 of the bytes) is all-reduced while lane 0 is still running
         self.buckets = agent.grad_buckets() if overlap else None
+        # a stream of our own: torch's default stream has the NULL handle, which the engine would read as "use your own stream" -
+        # and the collectives, issued on torch's current stream, must be ordered with the engine's graphs
+        self.main_stream = torch.cuda.Stream()
         if self.buckets is not None:
             self.side_stream = torch.cuda.Stream()
             (o0, n0), (o1, n1) = self.buckets
@@ -90,40 +93,43 @@ class DataParallelFQL:
 
     def update_from_dataset(self, n_rows, batch_size=None, idxs=None, noise=None):
         """One synchronous data-parallel step; indices are drawn from this rank's shard."""
-        import torch
         lo, hi = shard_range(n_rows, self.rank, self.world)
         if self.buckets is not None:
             self._overlapped(lambda s0, s1: self.agent.update_begin_split(s0, s1, idxs=idxs, shard=(lo, hi), batch_size=batch_size, noise=noise))
             return
-        st = torch.cuda.current_stream().cuda_stream
-        self.agent.update_begin(idxs=idxs, shard=(lo, hi), batch_size=batch_size, noise=noise, stream=st)
-        if self.world > 1 or self.always_reduce:
-            self.dist.all_reduce(self.grads, op=self.dist.ReduceOp.SUM, group=self.pg)
-        self.agent.update_end(stream=st)
+        self._plain(lambda st: self.agent.update_begin(idxs=idxs, shard=(lo, hi), batch_size=batch_size, noise=noise, stream=st))
+
+    def _plain(self, begin):
+        import torch
+        outer, main = torch.cuda.current_stream(), self.main_stream
+        main.wait_stream(outer)
+        with torch.cuda.stream(main):
+            begin(main.cuda_stream)
+            if self.world > 1 or self.always_reduce:
+                self.dist.all_reduce(self.grads, op=self.dist.ReduceOp.SUM, group=self.pg)
+            self.agent.update_end(stream=main.cuda_stream)
+        outer.wait_stream(main)
 
     def _overlapped(self, begin):
         import torch
-        main = torch.cuda.current_stream()
-        side = self.side_stream
+        outer, main, side = torch.cuda.current_stream(), self.main_stream, self.side_stream
+        main.wait_stream(outer)                      # earlier work of the caller first
         side.wait_stream(main)                       # lane 1 must not start before earlier work on the main stream
         begin(main.cuda_stream, side.cuda_stream)
         if self.world > 1 or self.always_reduce:
             with torch.cuda.stream(side):            # bucket 0 follows lane 1; overlaps the Euler chain on `main`
                 self.dist.all_reduce(self.g0, op=self.dist.ReduceOp.SUM, group=self.pg)
-            self.dist.all_reduce(self.g1, op=self.dist.ReduceOp.SUM, group=self.pg)
+            with torch.cuda.stream(main):
+                self.dist.all_reduce(self.g1, op=self.dist.ReduceOp.SUM, group=self.pg)
         main.wait_stream(side)
         self.agent.update_end(stream=main.cuda_stream)
+        outer.wait_stream(main)
 
     def update(self, batch, noise=None):
-        import torch
         if self.buckets is not None:
             self._overlapped(lambda s0, s1: self.agent.update_begin_split(s0, s1, batch=batch, noise=noise))
             return
-        st = torch.cuda.current_stream().cuda_stream
-        self.agent.update_begin(batch=batch, noise=noise, stream=st)
-        if self.world > 1:
-            self.dist.all_reduce(self.grads, op=self.dist.ReduceOp.SUM, group=self.pg)
-        self.agent.update_end(stream=st)
+        self._plain(lambda st: self.agent.update_begin(batch=batch, noise=noise, stream=st))
 
     def reduce_info(self, info):
         """Metrics across ranks at log time: means, except max/min entries."""

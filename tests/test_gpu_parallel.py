@@ -148,3 +148,44 @@ def test_dataset_mirror_attached_to_engine():
     a.update_from_dataset(B, idxs=idx, noise=nz)
     b.update(rb.sample(B, idxs=idx), noise=nz)
     assert a.read_info() == b.read_info()
+
+
+@pytest.mark.parametrize('overlap', [True, False])
+def test_data_parallel_wrapper_with_rccl_at_world_size_one(overlap):
+    """DataParallelFQL exactly as bench.py drives it (torch's DEFAULT stream current, collectives issued through torch.distributed /
+    RCCL even at world size 1): same step as the plain engine call, on the overlapped (bucketed) and the single-all-reduce path."""
+    import os
+    import torch.distributed as dist
+    import fql_amd
+    from fql_amd.parallel import DataParallelFQL
+    od, ad, B = 29, 8, 64
+    cfg, ds, batch, noise = make_problem(od, ad, B, (64, 64, 64, 64), seed=27)
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+        created = True
+    try:
+        a = fql_amd.FQLAgent.create(0, batch['observations'][:1], batch['actions'][:1], cfg)
+        b = fql_amd.FQLAgent.create(0, batch['observations'][:1], batch['actions'][:1], cfg)
+        a.upload_dataset(ds); b.upload_dataset(ds)
+        dp = DataParallelFQL(b, overlap=overlap)
+        dp.always_reduce = True
+        assert (dp.buckets is not None) == overlap
+        n = len(ds['observations'])
+        for step in range(3):
+            idxs = np.random.default_rng(step).integers(0, n, size=B)
+            nz = O.make_noise(B, ad, 100 + step)
+            a.update_from_dataset(B, idxs=idxs, noise=nz)
+            dp.update_from_dataset(n, batch_size=B, idxs=idxs, noise=nz)
+        torch.cuda.synchronize()
+        ia, ib = a.read_info(), b.read_info()
+        for k in ia:
+            assert abs(ia[k] - ib[k]) <= 1e-6 * max(1.0, abs(ia[k])), (k, ia[k], ib[k])
+        pa, pb = (dict(O.tree_leaves_with_path(x.get_params())) for x in (a, b))
+        for p in pa:
+            np.testing.assert_allclose(pb[p], pa[p], rtol=0, atol=1e-7, err_msg=p)
+    finally:
+        if created:
+            dist.destroy_process_group()
