@@ -1726,7 +1726,7 @@ struct fql_engine {
         // deferring the BC flow's too: 2161, the critic's whole backward chain: 2050).  FQL_LATE_WGRAD: 0 off, 1 both, 2 critic, 3 bc.
         static const int late_wgrad = getenv("FQL_LATE_WGRAD") ? atoi(getenv("FQL_LATE_WGRAD")) : 2;
         std::vector<Op> late_ops;
-        if ((late_wgrad == 1 || late_wgrad == 2) && with_grads && !split_build) defer_wgrads = &late_ops;
+        if ((late_wgrad == 1 || late_wgrad == 2) && with_grads) defer_wgrads = &late_ops;
         if (with_grads)
             for (int e = 0; e < 2; ++e) emit_backward(pr, p_c1[e], 0, B, true, visual);
         // (not in the data-parallel split program: there lane 1 must finish bucket 0 without waiting for lane 0's tail)
@@ -1747,7 +1747,7 @@ struct fql_engine {
             if (with_grads) op.writes.push_back(p_bc.dz.back());
             push(pr, op);
         }
-        defer_wgrads = ((late_wgrad == 1 || late_wgrad == 3) && with_grads && !split_build) ? &late_ops : nullptr;
+        defer_wgrads = ((late_wgrad == 1 || late_wgrad == 3) && with_grads) ? &late_ops : nullptr;
         if (with_grads) emit_backward(pr, p_bc, 0, B, true, visual);
         if (with_grads && visual && !enc_align) {
             place("enc", 1, true);
@@ -1814,7 +1814,7 @@ struct fql_engine {
             // cost ~10 us of tail instead.  (FQL_OS_WGRAD_SIDE=1: the old placement.)
             static const bool os_w_side = getenv("FQL_OS_WGRAD_SIDE") != nullptr;
             std::vector<Op> os_w;
-            if (!os_w_side && !split_build) defer_wgrads = &os_w;
+            if (!os_w_side) defer_wgrads = &os_w;
             const size_t first = pr.ops.size();
             emit_backward(pr, p_os_bwd, B, B, true, visual);
             defer_wgrads = nullptr;
