@@ -823,7 +823,6 @@ __device__ __forceinline__ void gemm64_body(const GemmTask& T, float* lds) {
                 if (flags & GF_GELU) v = gelu_f(v);
                 if (flags & GF_GELUGRAD) v *= gelu_grad_f(ldg(T.Zprev + o));
                 if (flags & GF_RELUGRAD) v = (ldg(T.Zprev + o) > 0.f) ? v : 0.f;
-        if (flags & GF_RELUGRAD) v = (ldg(T.Zprev + o) > 0.f) ? v : 0.f;
                 stg(T.C + o, v);
                 s1[i][r] += v; s2[i][r] += v * v;
             }
