@@ -1,0 +1,220 @@
+// Euler chain of the BC flow (agents/fql.py:155-171) on gfx950: the three launches of one Euler step as ONE
+// specialised kernel family.
+//
+// The chain is flow_steps x (4 hidden layers + head) strictly sequential [B x H] x [H x H] products: 30 launches
+// per update that are latency-bound, not throughput-bound (0.134 GFLOP each = 0.85 us of the chip's fp32 matrix
+// rate).  What a launch costs is its serial per-wave work, so this kernel halves all of it relative to the generic
+// 16-row kernel (fql_gemm16_kernel):
+//   * 512-thread workgroups on a 16 x 32 output tile: 8 waves = 2 column tiles x 4 K-quarters, 32 MFMAs per wave
+//     instead of 64, two waves per SIMD;
+//   * weights come from a FRAGMENT-MAJOR copy Wf[k/4][n][4] written once per update behind Adam
+//     (fql_wfrag_kernel): lane (c, q) of k-group g needs W[16g + 4q + s][n0 + c], s = 0..3, which is ONE 16-byte load
+//     there (four 4-byte loads of four different rows in the row-major arena).  The whole K-quarter of a wave is 8 such
+//     loads, all issued before anything else - no chunk loop;
+//   * the task is the kernel argument (no task-table hop through HBM before the first load can issue);
+//   * the K-quarter partials meet in LDS and the 8 waves share the epilogue (one output element per lane).
+// Variants (agents/fql.py:166-169):
+//   A  fold the previous step's head partials -> a_s ; layer 0 as a rank-(act + 1) update of the loop-invariant
+//      C0 = obs W0 + b0 ; GELU ; layer 1
+//   B  a middle hidden layer
+//   C  the last hidden layer + the action head as per-column-tile partials (folded by the next step's variant A, or by
+//      fql_euler_finish_kernel after the last step) - fixed summation order, deterministic.
+// Numerics: fp32 MFMA (v_mfma_f32_16x16x4_f32) = exact fp32 fma chains; only the summation ORDER over k differs from
+// the generic kernel (K quarters instead of halves).
+#pragma once
+#include "fql_kernels.h"
+
+#define FQL_CHAIN_THREADS 512
+
+struct ChainArgs {
+    const float* A;       // B, C: input activations [M, H] row-major.  A: C0 in C-fragment-major layout [M/4][H][4]
+    const float* Wf;      // fragment-major kernel of this launch's H x H layer: [H/4][H][4]
+    const float* bias;    // [H]
+    float* C;             // A, B: output activations [M, H] row-major
+    // variant A
+    const float* ea_in;   // [M, ea_ld] actions a_{s-1} (step 0: the noise z)
+    float* ea_out;        // [M, ap] a_s as used by this step (written by column tile 0) or null
+    const float* W0f;     // fragment-major W0 rows of (action block, t, zero padding): [4][H][4]
+    const float* evp_in;  // [H/32][M][ap] head partials of the previous step, or null (step 0)
+    const float* eb;      // [ap] head bias
+    // variant C
+    const float* W4f;     // fragment-major head kernel [H/4][ap][4]
+    float* evp_out;       // [H/32][M][ap]
+    int M, ad, ap, ea_ld;
+    float inv_steps, t_s;
+    int variant;          // 0 = A, 1 = B, 2 = C
+    unsigned long long* stamps;   // diagnostics build only (FQL_STAMPS): [grid][8] wall-clock stamps
+};
+
+// dst[(k >> 2) * N + n][k & 3] = src[k * ld + n]: the layout the chain kernel's B fragments are one dwordx4 in
+struct WfragTask {
+    const float* src;
+    float* dst;
+    int K, N, ld;     // K multiple of 4
+    int kvalid;       // rows [kvalid, K) are written as zeros (the rank-update block may run past the layer's padded input rows)
+    int tile0;        // first workgroup of this task
+};
+__global__ __launch_bounds__(FQL_THREADS) void fql_wfrag_kernel(const WfragTask* __restrict__ tasks, int ntasks) {
+    const WfragTask& T = tasks[find_task(tasks, ntasks, blockIdx.x)];
+    const int e = (blockIdx.x - T.tile0) * FQL_THREADS + threadIdx.x;   // one (k4, n) per thread
+    const int n = e % T.N, k4 = e / T.N;
+    if (k4 >= (T.K >> 2)) return;
+    f32x4 v;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v[s] = (4 * k4 + s < T.kvalid) ? ldg(T.src + (size_t)(4 * k4 + s) * T.ld + n) : 0.f;
+    stg4(T.dst + ((size_t)k4 * T.N + n) * 4, v);
+}
+
+template <int H>
+__global__ __launch_bounds__(FQL_CHAIN_THREADS) void fql_chain_kernel(const ChainArgs P) {
+    static_assert(H % 128 == 0 && H <= 1024, "hidden width must be a multiple of 128");
+    constexpr int S = H + 4;          // LDS row stride of the A tile (floats)
+    constexpr int GQ = H / 64;        // k-groups (of 16) per K-quarter
+    constexpr int NA = H / 128;       // float4 loads per thread that cover the 16 x H A tile
+    constexpr int CT = H / 128;       // layer-0 column tiles per wave (variant A)
+    constexpr int NT = H / 32;        // column tiles = head partials per row tile
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* red = lds + 16 * S;        // [4 K-quarters][2 column tiles][64 lanes] float4
+    float* ea = red + 4 * 2 * 64 * 4; // [16][32] actions of this step (variant A)
+    float* hs = ea + 512;             // [16][36] GELU tile feeding the head partial (variant C)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 15, q = lane >> 4;
+    const int nt = wave & 1, kp = wave >> 1;
+    const int tm = blockIdx.x / NT, tn = blockIdx.x - tm * NT;
+    const int row0 = tm * 16, n0 = tn * 32 + nt * 16;
+    const int variant = P.variant;
+#ifdef FQL_STAMPS
+    unsigned long long stamp[8];
+    int nst = 0;
+#define CSTAMP() do { __builtin_amdgcn_s_waitcnt(0); stamp[nst++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CSTAMP() do {} while (0)
+#endif
+    CSTAMP();
+    // ---- every load of the launch that does not depend on another workgroup's data of THIS launch goes out first
+    f32x4 bf[GQ];
+    {
+        const float* wb = P.Wf + ((size_t)(4 * kp * GQ + q) * H + n0 + c) * 4;
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) bf[g] = ldg4(wb + (size_t)g * 16 * H);   // k-group kp GQ + g: rows 4 (kp GQ + g) + q of Wf
+    }
+    const float bias = ldg(P.bias + n0 + c);
+    f32x4 bw4[2];
+    if (variant == 2 && wave == 0) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) bw4[g] = ldg4(P.W4f + ((size_t)(tn * 8 + 4 * g + q) * P.ap + c) * 4);
+    }
+    if (variant == 0) {
+        // layer 0: C0 (loop invariant) + [a_s | t_s | 0] (16 x 16) times the 16 rows of W0 that start at the action block
+        f32x4 cacc[CT], wf[CT];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int ct = wave + 8 * t;
+            cacc[t] = ldg4(P.A + ((size_t)((row0 >> 2) + q) * H + 16 * ct + c) * 4);   // C layout: rows 4q + i, column c
+            wf[t] = ldg4(P.W0f + ((size_t)q * H + 16 * ct + c) * 4);                   // k = 4q + s
+        }
+        {   // a_s = a_{s-1} + (sum of head partials + head bias) / flow_steps: two threads per element, fixed order
+            const int e = tid >> 1, half = tid & 1;
+            const int r = e >> 4, j = e & 15;
+            float a = 0.f;
+            if (j < P.ad) {
+                a = ldg(P.ea_in + (size_t)(row0 + r) * P.ea_ld + j);
+                if (P.evp_in) {
+                    float pv[NT / 2];
+                    const float* pp = P.evp_in + ((size_t)(half * (NT / 2)) * P.M + row0 + r) * P.ap + j;
+#pragma unroll
+                    for (int tp = 0; tp < NT / 2; ++tp) pv[tp] = ldg(pp + (size_t)tp * P.M * P.ap);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int tp = 0; tp < NT / 2; ++tp) sum += pv[tp];
+                    const float other = __shfl_xor(sum, 1);
+                    const float tot = half ? other + sum : sum + other;   // (partials 0..NT/2-1) + (NT/2..NT-1) on both lanes
+                    a += (tot + ldg(P.eb + j)) * P.inv_steps;
+                }
+                if (tn == 0 && half == 0 && P.ea_out) stg(P.ea_out + (size_t)(row0 + r) * P.ap + j, a);
+            } else if (j == P.ad) {
+                a = P.t_s;
+            }
+            if (half == 0) ea[r * 32 + j] = a;
+        }
+        CSTAMP();
+        __syncthreads();
+        {
+            const f32x4 af = *reinterpret_cast<const f32x4*>(&ea[c * 32 + 4 * q]);   // A'[row c][k = 4q + s]
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) cacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s4], wf[t][s4], cacc[t], 0, 0, 0);
+                const int ct = wave + 8 * t;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lds[(4 * q + i) * S + 16 * ct + c] = gelu_f(cacc[t][i]);
+            }
+        }
+    } else {
+        f32x4 av[NA];
+        const float* Ag = P.A + (size_t)row0 * H;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) av[i] = ldg4(Ag + (size_t)(tid + i * FQL_CHAIN_THREADS) * 4);   // 16 rows of H floats are contiguous
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int f = tid + i * FQL_CHAIN_THREADS;
+            const int r = f / (H / 4), kk = f - r * (H / 4);
+            *reinterpret_cast<f32x4*>(&lds[r * S + 4 * kk]) = av[i];
+        }
+        CSTAMP();
+    }
+    __syncthreads();
+    CSTAMP();
+    // ---- this wave's K-quarter: GQ k-groups x 4 MFMAs on two accumulator chains
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+    {
+        const float* arow = lds + c * S + 4 * q + 16 * kp * GQ;
+#pragma unroll
+        for (int g = 0; g < GQ; g += 2) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * g);
+            const f32x4 a2 = *reinterpret_cast<const f32x4*>(arow + 16 * g + 16);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], bf[g][s4], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[s4], bf[g + 1][s4], acc2, 0, 0, 0);
+            }
+        }
+        acc += acc2;
+    }
+    *reinterpret_cast<f32x4*>(&red[((kp * 2 + nt) * 64 + lane) * 4]) = acc;
+    CSTAMP();
+    __syncthreads();
+    // ---- epilogue shared by the 8 waves: wave (nt, kp) finishes row 4q + kp, column n0 + c of its column tile
+    float v = bias;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) v += red[((p * 2 + nt) * 64 + lane) * 4 + kp];
+    v = gelu_f(v);
+    const int row = row0 + 4 * q + kp;
+    if (variant != 2) {
+        stg(P.C + (size_t)row * H + n0 + c, v);
+    } else {
+        hs[(4 * q + kp) * 36 + 16 * nt + c] = v;
+        __syncthreads();
+        if (wave == 0) {   // 16 x 32 GELU tile times this workgroup's 32 rows of the head kernel
+            f32x4 pa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(&hs[c * 36 + 16 * g + 4 * q]);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) pa = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s4], bw4[g][s4], pa, 0, 0, 0);
+            }
+            if (c < P.ap) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) stg(P.evp_out + ((size_t)tn * P.M + row0 + 4 * q + i) * P.ap + c, pa[i]);
+            }
+        }
+    }
+#ifdef FQL_STAMPS
+    CSTAMP();
+    if (lane == 0 && wave == 0 && P.stamps) {
+        unsigned long long* d = P.stamps + (size_t)blockIdx.x * 8;
+        for (int i = 0; i < nst; ++i) d[i] = stamp[i];
+    }
+#endif
+}
+#define FQL_CHAIN_LDS_BYTES(H) ((size_t)(16 * ((H) + 4) + 4 * 2 * 64 * 4 + 512 + 16 * 36) * sizeof(float))

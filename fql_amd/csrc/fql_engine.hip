@@ -12,6 +12,7 @@
 #include "../../include/fql_amd.h"
 #include "fql_kernels.h"
 #include "fql_conv.h"
+#include "fql_chain.h"
 
 #include <algorithm>
 #include <cmath>
@@ -113,7 +114,8 @@ struct Leaf {
 // program = ordered ops with read/write sets -> levels -> launches
 // ------------------------------------------------------------------------------------------------
 enum OpType { OP_GEMM, OP_GEMM64, OP_WGRAD, OP_LNBWD, OP_PREP, OP_POSTOS, OP_EULER_FIN, OP_PEC, OP_LOSS_CRITIC, OP_LOSS_Q, OP_LOSS_BC,
-              OP_LOSS_ACTOR, OP_CONV_WPREP, OP_CONV, OP_CONV_U8, OP_POOL, OP_POOL_BWD, OP_CONV_WGRAD, OP_CONV_WRED, OP_ENC_DZ, OP_ADAM, OP_FINALIZE };
+              OP_LOSS_ACTOR, OP_CONV_WPREP, OP_CONV, OP_CONV_U8, OP_POOL, OP_POOL_BWD, OP_CONV_WGRAD, OP_CONV_WRED, OP_ENC_DZ, OP_CHAIN, OP_WFRAG, OP_ADAM,
+              OP_FINALIZE };
 
 struct Op {
     OpType type;
@@ -135,6 +137,7 @@ struct Op {
     ConvWgradArgs cw;
     ConvWredArgs cwr;
     EncDzArgs edz;
+    ChainArgs chain;
     const ConvWprepTask* wprep_tasks = nullptr;
     int wprep_n = 0;
     int cw_grid = 0;
@@ -244,6 +247,14 @@ struct fql_engine {
     float *vel = nullptr, *w_rew = nullptr, *w_mask = nullptr, *w_act = nullptr, *tgt = nullptr;
     float *X_e0 = nullptr, *C0 = nullptr, *Abuf[2] = {nullptr, nullptr}, *Vpart = nullptr;  // fused Euler chain
     bool fused_euler = false, use_pec = false;
+    // Euler-chain kernel (fql_chain.h): fragment-major copies of the BC flow's hidden kernels (layers 1..nh-1), of the 16 rows of
+    // W0 that start at the action block and of the head kernel, refreshed behind every Adam step of that module
+    bool use_chain = false;
+    std::vector<float*> wf_bc;       // per layer 1..nh-1: [H/4][H][4]
+    float *wf_w0 = nullptr, *wf_w4 = nullptr;
+    WfragTask* d_wfrag = nullptr;
+    int wfrag_n = 0, wfrag_grid = 0;
+    std::vector<void*> chain_allocs;
     bool split_build = false;   // building the data-parallel program: lane 1 must not depend on lane 0's backward
     bool split_ok = false;
     int vp_tiles = 0;
@@ -400,6 +411,41 @@ struct fql_engine {
             enc_wprep[ei] = (ConvWprepTask*)dalloc(enc_allocs, tasks.size() * sizeof(ConvWprepTask) / sizeof(float) + 4);
             HIP_CHECK(hipMemcpy(enc_wprep[ei], tasks.data(), tasks.size() * sizeof(ConvWprepTask), hipMemcpyHostToDevice));
         }
+    }
+
+    // Fragment-major weight copies for fql_chain_kernel (needs P): BC flow with >= 3 equal hidden layers of width 256 / 512
+    void build_chain_weights() {
+        const Net& n = nets[NET_BC];
+        const int nh = n.nl() - 1;
+        const int H = n.layers[0].out_p;
+        bool ok = getenv("FQL_NO_CHAIN") == nullptr && !cfg.actor_layer_norm && cfg.act_dim <= 15 && nh >= 3 && (H == 256 || H == 512);
+        for (int l = 0; l < nh && ok; ++l) ok = n.layers[l].out == H && n.layers[l].out_p == H;
+        use_chain = ok;
+        if (!ok) return;
+        const int od = cfg.obs_dim, ap = pad16(cfg.act_dim);
+        std::vector<WfragTask> tasks;
+        int tile = 0;
+        auto add = [&](const float* src, int K, int N, int ld, int kvalid) {
+            float* dst = dalloc(chain_allocs, (size_t)K * N);
+            tasks.push_back(WfragTask{src, dst, K, N, ld, kvalid, tile});
+            tile += ((K / 4) * N + FQL_THREADS - 1) / FQL_THREADS;
+            return dst;
+        };
+        wf_bc.clear();
+        for (int l = 1; l < nh; ++l) wf_bc.push_back(add(P + n.layers[l].w, H, H, H, H));
+        const Layer& l0 = n.layers[0];
+        wf_w0 = add(P + l0.w + (size_t)od * l0.out_p, 16, H, l0.out_p, std::min(16, l0.in_p - od));   // rows of (action block, t, padding)
+        wf_w4 = add(P + n.layers[nh].w, H, ap, ap, H);
+        wfrag_n = (int)tasks.size(); wfrag_grid = tile;
+        d_wfrag = (WfragTask*)dalloc(chain_allocs, tasks.size() * sizeof(WfragTask) / sizeof(float) + 4);
+        HIP_CHECK(hipMemcpy(d_wfrag, tasks.data(), tasks.size() * sizeof(WfragTask), hipMemcpyHostToDevice));
+    }
+    // after any out-of-graph parameter write (init, fql_set_param): bring the copies up to date
+    void refresh_chain_weights(hipStream_t s) {
+        if (!use_chain) return;
+        hipLaunchKernelGGL(fql_wfrag_kernel, dim3(wfrag_grid), dim3(FQL_THREADS), 0, s, (const WfragTask*)d_wfrag, wfrag_n);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(s));
     }
 
     void build_leaves() {
@@ -982,6 +1028,7 @@ struct fql_engine {
                     if (s >= 1) {
                         t.evp = Vpart; t.eb = P + n.layers[nh].b; t.e_ntp = vp_tiles; t.ea_out = Abuf[s & 1];
                         op.reads.push_back(Vpart);
+                        op.reads.push_back(P + n.layers[nh].w);
                         op.writes.push_back(Abuf[s & 1]);
                     }
                 } else {
@@ -1006,8 +1053,86 @@ struct fql_engine {
         const bool from_x = fs == 1;
         op.ef = EulerFinishArgs{from_x ? X_eu + od : Abuf[(fs - 1) & 1], Vpart, P + n.layers[nh].b, tgt, B, ad, ap, vp_tiles,
                                 from_x ? inp_b : ap, 1.0f / (float)fs};
-        op.reads = {from_x ? (const void*)X_eu : (const void*)Abuf[(fs - 1) & 1], Vpart};
+        op.reads = {from_x ? (const void*)X_eu : (const void*)Abuf[(fs - 1) & 1], Vpart, P + n.layers[nh].w};   // (head bias: WAR against Adam)
         op.writes = {tgt};
+        push(pr, op);
+    }
+
+    // The same 3-launches-per-step chain on fql_chain_kernel (512-thread workgroups, fragment-major weights, kernarg tasks)
+    void emit_euler_chain(Program& pr) {
+        const Net& n = nets[NET_BC];
+        const int nh = n.nl() - 1, fs = cfg.flow_steps;
+        const int od = cfg.obs_dim, ad = cfg.act_dim, ap = pad16(ad), inp_b = n.in_p();
+        const Layer& l0 = n.layers[0];
+        {
+            Op op{};
+            op.type = OP_GEMM;
+            GemmTask& t = op.gemm;
+            t.A = X_e0; t.lda = l0.in_p; t.B = P + l0.w; t.ldb = l0.out_p; t.bias = P + l0.b; t.C = C0; t.ldc = l0.out_p;
+            t.M = B; t.N = l0.out_p; t.K = l0.in_p; t.flags = GF_BIAS | GF_C_FRAG;
+            op.reads = {X_e0, t.B};
+            op.writes = {C0};
+            push(pr, op);
+        }
+        for (int s = 0; s < fs; ++s) {
+            for (int l = 1; l < nh; ++l) {
+                const Layer& ly = n.layers[l];
+                Op op{};
+                op.type = OP_CHAIN;
+                ChainArgs& a = op.chain;
+                a.Wf = wf_bc[l - 1]; a.bias = P + ly.b;
+                a.M = B; a.ad = ad; a.ap = ap;
+                a.inv_steps = 1.0f / (float)fs; a.t_s = (float)s / (float)fs;
+                a.variant = 1;
+                op.reads = {a.Wf, P + ly.w};
+                if (l == 1) {
+                    a.variant = 0;
+                    a.A = C0; a.W0f = wf_w0;
+                    if (s <= 1) { a.ea_in = X_eu + od; a.ea_ld = inp_b; } else { a.ea_in = Abuf[(s - 1) & 1]; a.ea_ld = ap; }
+                    op.reads.push_back(C0);
+                    op.reads.push_back(wf_w0);
+                    op.reads.push_back((s <= 1) ? (const void*)X_eu : (const void*)Abuf[(s - 1) & 1]);
+                    if (s >= 1) {
+                        a.evp_in = Vpart; a.eb = P + n.layers[nh].b; a.ea_out = Abuf[s & 1];
+                        op.reads.push_back(Vpart);
+                        op.reads.push_back(P + n.layers[nh].w);
+                        op.writes.push_back(Abuf[s & 1]);
+                    }
+                } else {
+                    a.A = p_eu.g[l - 1];
+                    op.reads.push_back(a.A);
+                }
+                if (l == nh - 1) {   // nh >= 3: never the same launch as variant A
+                    a.variant = 2;
+                    a.W4f = wf_w4; a.evp_out = Vpart;
+                    op.reads.push_back(wf_w4);
+                    op.writes.push_back(Vpart);
+                } else {
+                    a.C = p_eu.g[l];
+                    op.writes.push_back(a.C);
+                }
+                push(pr, op);
+            }
+        }
+        Op op{};
+        op.type = OP_EULER_FIN;
+        const bool from_x = fs == 1;
+        op.ef = EulerFinishArgs{from_x ? X_eu + od : Abuf[(fs - 1) & 1], Vpart, P + n.layers[nh].b, tgt, B, ad, ap, vp_tiles,
+                                from_x ? inp_b : ap, 1.0f / (float)fs};
+        op.reads = {from_x ? (const void*)X_eu : (const void*)Abuf[(fs - 1) & 1], Vpart, P + n.layers[nh].w};   // (head bias: WAR against Adam)
+        op.writes = {tgt};
+        push(pr, op);
+    }
+    // refresh of the fragment-major copies inside a program, behind the Adam launch that rewrites the BC flow's kernels
+    void emit_wfrag(Program& pr) {
+        if (!use_chain) return;
+        const Net& n = nets[NET_BC];
+        Op op{};
+        op.type = OP_WFRAG;
+        for (const Layer& L : n.layers) op.reads.push_back(P + L.w);
+        for (float* w : wf_bc) op.writes.push_back(w);
+        op.writes.push_back(wf_w0);
+        op.writes.push_back(wf_w4);
         push(pr, op);
     }
 
@@ -1539,6 +1664,13 @@ struct fql_engine {
                     hipLaunchKernelGGL(fql_enc_dz_kernel, dim3((a.M * a.n + FQL_THREADS - 1) / FQL_THREADS), dim3(FQL_THREADS), 0, s, a);
                     break;
                 }
+                case OP_CHAIN:
+                    if (cfg.actor_hidden[0] == 512) hipLaunchKernelGGL((fql_chain_kernel<512>), dim3((L.op.chain.M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, L.op.chain);
+                    else hipLaunchKernelGGL((fql_chain_kernel<256>), dim3((L.op.chain.M / 16) * 8), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(256), s, L.op.chain);
+                    break;
+                case OP_WFRAG:
+                    hipLaunchKernelGGL(fql_wfrag_kernel, dim3(wfrag_grid), dim3(FQL_THREADS), 0, s, (const WfragTask*)d_wfrag, wfrag_n);
+                    break;
                 case OP_ADAM: {
                     AdamArgs a{P, G, Mu, Nu, P + n_train, d_chunks, d_state, d_partials, L.op.adam_c0, (int)critic_size, cfg.lr, cfg.tau};
                     hipLaunchKernelGGL(fql_adam_kernel, dim3(L.op.adam_n < 0 ? n_chunks : L.op.adam_n), dim3(FQL_THREADS), 0, s, a);
@@ -1781,6 +1913,7 @@ struct fql_engine {
         place("eu", 0, false);
         const int fs = cfg.flow_steps;
         if (use_pec) emit_euler_persistent(pr);
+        else if (fused_euler && use_chain) emit_euler_chain(pr);
         else if (fused_euler) emit_euler_fused(pr);
         else
         for (int s = 0; s < fs; ++s)
@@ -1873,6 +2006,11 @@ struct fql_engine {
         a.reads = {st, G};
         a.writes = {P, Mu, Nu, INFO};
         push(pr, a);
+        if (use_chain) {   // the Adam op above names the whole arena as P: order the refresh behind it explicitly
+            const size_t i0 = pr.ops.size();
+            emit_wfrag(pr);
+            pr.ops[i0].reads.push_back(P);
+        }
         Op f{};
         f.type = OP_FINALIZE;
         f.fin_mode = 1;
@@ -1917,6 +2055,7 @@ struct fql_engine {
         };
         adam_for(2, {NET_C0, NET_C1}, 1);
         adam_for(0, {NET_BC}, 1);
+        emit_wfrag(pr);   // lane 1, behind the BC flow's Adam: the next update's chain reads the copies
         adam_for(1, {NET_OS}, 0);
         Op f{};
         f.type = OP_FINALIZE;
@@ -1986,7 +2125,7 @@ struct fql_engine {
         {   // fused Euler chain (layers 0+1 and last-hidden+head per launch): plain actor MLPs with >= 2 hidden layers
             const Net& nb = nets[NET_BC];
             const int nh = nb.nl() - 1;
-            fused_euler = getenv("FQL_NO_FUSED_EULER") == nullptr && !cfg.actor_layer_norm && ad <= 16 && nh >= 3;
+            fused_euler = getenv("FQL_NO_FUSED_EULER") == nullptr && !cfg.actor_layer_norm && ad <= 15 && nh >= 3;   // 16-wide rank update: act + t
             if (fused_euler) {
                 X_e0 = dalloc(W, (size_t)B * inp_b);
                 C0 = dalloc(W, (size_t)B * nb.layers[0].out_p);
@@ -2396,6 +2535,8 @@ int fql_create(const fql_config* cfg, uint64_t seed, fql_handle* out) {
         h->build_enc_weights();
         h->build_leaves();
         h->init_params();
+        h->build_chain_weights();
+        h->refresh_chain_weights(h->stream);
         HIP_CHECK(hipMalloc((void**)&h->d_state, sizeof(DevState)));
         HIP_CHECK(hipMalloc((void**)&h->d_src, sizeof(SrcDesc)));
         HIP_CHECK(hipHostMalloc((void**)&h->h_src_ring, 64 * sizeof(SrcDesc), hipHostMallocDefault));
@@ -2428,6 +2569,7 @@ int fql_destroy(fql_handle h) {
     hipFree(h->ds_obs); hipFree(h->ds_act); hipFree(h->ds_rew); hipFree(h->ds_mask); hipFree(h->ds_nobs); hipFree(h->ds_row);
     hipFree(h->ds_frames); hipFree(h->ds_next_frames); hipFree(h->ds_init);
     for (void* q : h->enc_allocs) hipFree(q);
+    for (void* q : h->chain_allocs) hipFree(q);
     if (h->stream) hipStreamDestroy(h->stream);
     if (h->stream2) hipStreamDestroy(h->stream2);
     if (h->stream3) hipStreamDestroy(h->stream3);
@@ -2472,6 +2614,7 @@ static int leaf_rw(fql_handle h, const char* leaf, float* host, size_t n, int wh
             arena = which == 0 ? h->Mu : h->Nu;
         }
         h->leaf_io(*l, arena, host, to_device);
+        if (to_device && which < 0 && l->name.rfind("modules_actor_bc_flow/", 0) == 0) h->refresh_chain_weights(h->stream);
         return FQL_OK;
     } catch (const Invalid& e) { h->err = e.msg; return FQL_E_INVALID; }
     catch (const HipError& e) { h->err = e.msg; return FQL_E_HIP; }

@@ -43,6 +43,8 @@ enum : int {
     GF_A_LOSSACT = 1 << 17,  // A tile = d(actor loss)/d(one-step actions) built in the prologue (agents/fql.py:66-79): no loss kernel on the critical path
     GF_RELUGRAD = 1 << 14,   // epilogue: C = (Zprev > 0) ? acc : 0  (dgrad through the encoder's final ReLU, utils/encoders.py:92)
     GF_LN_PART = 1 << 10,   // gemm64 epilogue: per-row (sum, sum sq) of this 64-column tile -> aux[row][i1 tiles][2]
+    GF_C_FRAG = 1 << 18,    // gemm16 epilogue: C (+ bias) stored in accumulator-fragment-major layout [M/4][N][4] (one dwordx4 per lane;
+                            // read back as one dwordx4 per MFMA tile by fql_chain_kernel variant A)
 };
 
 struct GemmTask {
@@ -115,6 +117,7 @@ __device__ __forceinline__ float fast_tanh(float u) {
     const float t = (1.0f - e) * __frcp_rn(1.0f + e);
     return copysignf(t, u);
 }
+#ifdef FQL_GELU_TANH   // the round-1 form (kept for A/B measurements)
 __device__ __forceinline__ float gelu_f(float x) {
     // flax nn.gelu (approximate=True): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
     const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
@@ -126,6 +129,31 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     const float du = 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
     return 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * du;
 }
+#else
+// flax nn.gelu (approximate=True) = 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3)   (utils/networks.py:46).
+// 0.5 (1 + tanh u) = sigmoid(2u) = 1 / (1 + exp(-2u)), so GELU = x / (1 + e) with e = exp2(x (C0 + C1 x^2)),
+// C0 = -2 sqrt(2/pi) log2(e), C1 = 0.044715 C0: five VALU ops + v_exp_f32 + v_rcp_f32 (the tanh form cost ~15 + 2; this sits in
+// every layer epilogue and, 16 x 512 times per workgroup, in the first launch of every Euler step).  e is clamped at 1e30 so
+// that e / (1 + e) stays finite for very negative x (GELU -> x * 1e-30 ~ -0).
+#define FQL_GELU_C0 (-2.302208198f)
+#define FQL_GELU_C1 (-0.1029432427f)
+__device__ __forceinline__ void gelu_core(float x, float& r, float& e, float& x2) {
+    x2 = x * x;
+    e = fminf(__builtin_amdgcn_exp2f(x * fmaf(FQL_GELU_C1, x2, FQL_GELU_C0)), 1e30f);
+    r = __builtin_amdgcn_rcpf(1.0f + e);   // sigmoid(2u)
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    float r, e, x2;
+    gelu_core(x, r, e, x2);
+    return x * r;
+}
+// d/dx [x s(2u)] = s + x s (1 - s) (2u)',  (2u)' = 2 sqrt(2/pi) (1 + 3 * 0.044715 x^2),  1 - s = e r
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    float r, e, x2;
+    gelu_core(x, r, e, x2);
+    return r * fmaf(x * (e * r), fmaf(0.2140644f, x2, 1.5957691216f), 1.0f);
+}
+#endif
 __device__ __forceinline__ float clip1(float x) { return fminf(fmaxf(x, -1.0f), 1.0f); }
 
 // Philox4x32-10 (Salmon et al. 2011), counter-based: the engine's own RNG stream (the reference's
@@ -583,6 +611,16 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
 
     // ---- epilogue. C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
     const int n = n0 + c;
+    if (flags & GF_C_FRAG) {
+#pragma unroll
+        for (int rt = 0; rt < TMT; ++rt) {
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = acc[rt][i] + bias;
+            stg4(T.C + ((size_t)(((row0 + 16 * rt) >> 2) + q) * T.ldc + n) * 4, o);
+        }
+        return;
+    }
 #pragma unroll
     for (int rt = 0; rt < TMT; ++rt) {
 #pragma unroll
@@ -954,11 +992,18 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_wgrad_kernel(const WgradTask*
 // groups per workgroup, fixed summation order (deterministic).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void gelu_both(float x, float& g, float& dg) {
+#ifdef FQL_GELU_TANH
     const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
     const float th = fast_tanh(u);
     const float du = 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
     g = 0.5f * x * (1.0f + th);
     dg = 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * du;
+#else
+    float r, e, x2;
+    gelu_core(x, r, e, x2);
+    g = x * r;
+    dg = r * fmaf(x * (e * r), fmaf(0.2140644f, x2, 1.5957691216f), 1.0f);
+#endif
 }
 template <bool SYN>  // SYN: dY[m][k] = dq[m] * wq[k] (scalar head), else dY is read from memory
 __device__ __forceinline__ void lnbwd_body(const LnBwdTask& T, int bid, float (*red)[16][16]) {
