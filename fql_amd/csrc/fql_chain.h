@@ -43,6 +43,7 @@ struct ChainArgs {
     int M, ad, ap, ea_ld;
     float inv_steps, t_s;
     int variant;          // 0 = A, 1 = B, 2 = C
+    int prio;             // s_setprio level of the chain's waves (they are latency-critical and light: 0.85 us of MFMA per launch)
     unsigned long long* stamps;   // diagnostics build only (FQL_STAMPS): [grid][8] wall-clock stamps
 };
 
@@ -83,6 +84,9 @@ __global__ __launch_bounds__(FQL_CHAIN_THREADS) void fql_chain_kernel(const Chai
     const int tm = blockIdx.x / NT, tn = blockIdx.x - tm * NT;
     const int row0 = tm * 16, n0 = tn * 32 + nt * 16;
     const int variant = P.variant;
+    if (P.prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (P.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (P.prio == 1) __builtin_amdgcn_s_setprio(1);
 #ifdef FQL_STAMPS
     unsigned long long stamp[8];
     int nst = 0;

@@ -180,7 +180,7 @@ struct PassBuf {
     const void* id = nullptr;          // dependency id base
     float* x0 = nullptr;               // [M, in_p]
     std::vector<float*> g, xn, z, stats;  // per hidden layer
-    std::vector<float*> lnpart;        // LN layers: per-row partial sums per 64-column tile (gemm64 path)
+    std::vector<float*> lnpart;        // LN layers: per-row partial sums per 32 columns (LDS-tiled kernels)
     float* out = nullptr;              // [M, out_p]
     std::vector<float*> dz;            // per layer gradient wrt pre-activation / output
     std::vector<float*> dy;            // LN nets: gradient wrt LN output
@@ -618,7 +618,7 @@ struct fql_engine {
             if (n.layers[l].ln) {
                 p.xn.push_back(dalloc(owner, (size_t)M * H));
                 p.stats.push_back(dalloc(owner, (size_t)M * 2));
-                p.lnpart.push_back(dalloc(owner, (size_t)M * ((2 * ((H + 63) / 64) + 3) & ~3)));
+                p.lnpart.push_back(dalloc(owner, (size_t)M * ((2 * ((H + 31) / 32) + 3) & ~3)));   // (sum, sum sq) per 32 columns
             } else {
                 p.xn.push_back(p.g.back());
                 p.stats.push_back(nullptr);
@@ -929,10 +929,12 @@ struct fql_engine {
                 t.flags |= GF_GELU;
                 if (save) { t.flags |= GF_SAVE_Z; t.Zout = p.z[l]; op.writes.push_back(t.Zout); }
                 op.writes.push_back(t.C);
-                if (want64(t.M, t.N, t.K, t.flags)) {
+                // LDS-tiled kernel; a LayerNorm'd A operand needs the producing layer's partial sums, i.e. that layer on it too
+                const bool prev64 = l > 0 && want64(p.M, n.layers[l - 1].out_p, n.layers[l - 1].in_p, GF_BIAS | GF_GELU);
+                if (want64(t.M, t.N, t.K, t.flags) && (!a_ln || prev64)) {
                     op.type = OP_GEMM64;
-                    if (a_ln) { t.aux2 = p.lnpart[l - 1]; t.i0 = t.K / 64; op.reads.push_back(t.aux2); }
-                    if (ly.ln) { t.flags |= GF_LN_PART; t.aux = p.lnpart[l]; t.i1 = t.N / 64; op.writes.push_back(t.aux); }
+                    if (a_ln) { t.aux2 = p.lnpart[l - 1]; t.i0 = t.K / 32; op.reads.push_back(t.aux2); }
+                    if (ly.ln) { t.flags |= GF_LN_PART; t.aux = p.lnpart[l]; t.i1 = t.N / 32; op.writes.push_back(t.aux); }
                 }
             } else {
                 t.C = p.out;
@@ -1084,6 +1086,8 @@ struct fql_engine {
                 a.M = B; a.ad = ad; a.ap = ap;
                 a.inv_steps = 1.0f / (float)fs; a.t_s = (float)s / (float)fs;
                 a.variant = 1;
+                static const int chain_prio = getenv("FQL_CHAIN_PRIO") ? atoi(getenv("FQL_CHAIN_PRIO")) : 0;
+                a.prio = chain_prio;
                 op.reads = {a.Wf, P + ly.w};
                 if (l == 1) {
                     a.variant = 0;
@@ -1320,12 +1324,34 @@ struct fql_engine {
                     int ri = 1;
                     int tile = 0;
                     std::vector<GemmTask> tg;
+                    // tile shape of the 32-row tasks of this launch: 32 x 64 unless 32 x 32 tiles deal out more evenly over the CUs
+                    // (e.g. 384 tiles of 32 x 64 = two tile times on half the CUs; 768 of 32 x 32 = three half-size tiles everywhere)
+                    static const int nj_env = getenv("FQL_TILE_NJ") ? atoi(getenv("FQL_TILE_NJ")) : 0;
+                    int nj = 2;
+                    {
+                        int t64 = 0;
+                        double other = 0.0;   // in units of a 32 x 32 x 512 tile
+                        for (const Op* o : sel) {
+                            const GemmTask& t = o->gemm;
+                            const bool big = ri_env ? ri_env == 2 : (t.M >= 1024 && t.M % 64 == 0);
+                            if (big) other += 4.0 * (t.M / 64) * (t.N / 64) * t.K / 512.0;
+                            else t64 += (t.M / 32) * (t.N / 64);
+                        }
+                        for (const Op* o : selw) other += 0.5 * (o->wgrad.Kin / 16) * ((o->wgrad.N + 63) / 64) * o->wgrad.M / 256.0;
+                        for (const Op* o : sell) other += 0.05 * o->ln.M;
+                        const int ncu = std::max(1, num_cus);
+                        const double m64 = 2.0 * ((t64 + ncu - 1) / ncu) + other / ncu, m32 = 1.0 * ((2 * t64 + ncu - 1) / ncu) + other / ncu;
+                        if (t64 > 0 && m32 < m64) nj = 1;
+                        if (nj_env == 1 || nj_env == 2) nj = nj_env;
+                    }
                     for (const Op* o : sel) {
                         GemmTask t = o->gemm;
                         const int ri_t = ri_env ? ri_env : (t.M >= 1024 && t.M % 64 == 0 ? 2 : 1);
                         ri = std::max(ri, ri_t);
-                        t.wk = 1; t.tmt = ri_t;
-                        t.ntn = t.N / 64; t.tile0 = tile;
+                        if (ri_t == 2) L.tmt2 = true;
+                        t.tmt = ri_t;
+                        t.wk = ri_t == 2 ? 2 : nj;          // MFMA column tiles per wave: tile = 32 x (32 wk)
+                        t.ntn = t.N / (32 * t.wk); t.tile0 = tile;
                         tile += (t.M / (32 * ri_t)) * t.ntn;
                         tg.push_back(t);
                     }
@@ -1359,7 +1385,10 @@ struct fql_engine {
                     }
                     L.grid = L.tile_m + (int)tmisc.size();
                     L.ntasks = (int)tg.size(); L.n_w = (int)tw.size(); L.n_l = (int)tl.size();
-                    L.lds = sizeof(float) * (tg.empty() ? (size_t)FQL_WGRAD_LDS_FLOATS : (size_t)(2 * (32 * ri + 64) * 68 + 256));
+                    L.lds = sizeof(float) * (tg.empty() ? (size_t)FQL_WGRAD_LDS_FLOATS
+                                             : ri == 2 ? (size_t)(2 * (32 * ri + 64) * 68 + 256)
+                                             : nj == 1 ? (size_t)(2 * 32 * 68 + 2 * 64 * 36 + 128) : (size_t)(2 * 32 * 68 + 2 * 64 * 68 + 128));
+                    L.lds = std::max(L.lds, sizeof(float) * (size_t)((selw.empty() ? 0 : FQL_WGRAD_LDS_FLOATS)));
                     auto up = [&](const void* src, size_t bytes) -> void* {
                         void* d = dalloc(owner, bytes / sizeof(float) + 4);
                         if (bytes) HIP_CHECK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
@@ -1467,7 +1496,7 @@ struct fql_engine {
                         GemmTask t = o->gemm;
                         static const int ri_env = getenv("FQL_G64_RI") ? atoi(getenv("FQL_G64_RI")) : 0;
                         const int ri = ri_env ? ri_env : (t.M >= 1024 && t.M % 64 == 0 ? 2 : 1);
-                        t.wk = 1; t.tmt = ri;  // row tiles per wave: workgroup tile (32 ri) x 64
+                        t.wk = 2; t.tmt = ri;  // row tiles per wave: workgroup tile (32 ri) x 64
                         t.ntn = t.N / 64;
                         t.tile0 = tile;
                         tile += (t.M / (32 * ri)) * t.ntn;
@@ -1590,8 +1619,12 @@ struct fql_engine {
                     else hipLaunchKernelGGL((fql_gemm16_kernel<false, false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
                     break;
                 case OP_GEMM64:
-                    if (L.side)
-                        hipLaunchKernelGGL(fql_side_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks,
+                    if (L.side && L.tmt2)
+                        hipLaunchKernelGGL((fql_side_kernel<true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks,
+                                           (const WgradTask*)L.table_w, L.n_w, (const LnBwdTask*)L.table_l, L.n_l, L.tile_w, L.tile_l,
+                                           (const MiscTask*)L.table_m, L.tile_m);
+                    else if (L.side)
+                        hipLaunchKernelGGL((fql_side_kernel<false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks,
                                            (const WgradTask*)L.table_w, L.n_w, (const LnBwdTask*)L.table_l, L.n_l, L.tile_w, L.tile_l,
                                            (const MiscTask*)L.table_m, L.tile_m);
                     else

@@ -78,6 +78,9 @@ struct GemmTask {
     float* evp;          // head partials [ntiles][M][ap]: read by A_EULER0 (null on step 0), written by HEAD_PART
     const float* eb;     // head bias [ap]
     int e_ntp;           // number of partial tiles to fold (A_EULER0)
+#ifdef FQL_STAMPS
+    unsigned long long* stamps64;   // diagnostics build: gemm64 phase stamps [workgroup][8]
+#endif
 };
 
 struct WgradTask {
@@ -703,6 +706,33 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_gemm16_euler_kernel(const Gem
 // them in fixed order (deterministic) into mean / rstd before staging (utils/networks.py:58).
 // ------------------------------------------------------------------------------------------------
 #define G64_S 68  // LDS row stride (floats): 64 + 4, keeps 16-byte alignment and spreads banks
+// Fold the per-32-column LayerNorm partial sums (sum, sum of squares) of NR rows (row_first + 16 i) in fixed order: 2 partials per
+// float4, batches of 8 float4 per row (a second batch only for widths above 512), rows padded to 16 bytes.
+template <int NR>
+__device__ __forceinline__ void ln_fold_partials(const float* __restrict__ partials, int row_first, int ntin, float (&sum)[NR], float (&sumsq)[NR]) {
+    const int rs = (2 * ntin + 3) & ~3;
+    const int nf4 = (ntin + 1) >> 1;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { sum[i] = 0.f; sumsq[i] = 0.f; }
+    for (int base = 0; base < nf4; base += 8) {   // uniform trip count (1 for widths <= 512)
+        f32x4 pv[NR][8];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const float* pp = partials + (size_t)(row_first + 16 * i) * rs;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) pv[i][t] = ldg4(pp + 4 * min(base + t, nf4 - 1));
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (2 * (base + t) < ntin) { sum[i] += pv[i][t][0]; sumsq[i] += pv[i][t][1]; }
+                if (2 * (base + t) + 1 < ntin) { sum[i] += pv[i][t][2]; sumsq[i] += pv[i][t][3]; }
+            }
+    }
+}
+
+
 // RI = 16-row MFMA tiles per wave along M: 2 -> 64 x 64 workgroup tile, 1 -> 32 x 64 (half the serial MFMA time per
 // workgroup and twice the workgroups: the side lane's levels are latency chains too, so the smaller tile wins there)
 template <bool transb, int RI>
@@ -721,6 +751,14 @@ __device__ __forceinline__ void gemm64_body(const GemmTask& T, float* lds) {
     const int flags = T.flags;
     const bool a_ln = (flags & GF_A_LN) != 0;
     const bool ln_wr = (flags & GF_LN_WRITE) && tn == 0;
+#ifdef FQL_STAMPS
+    unsigned long long stamp[8];
+    int nst = 0;
+#define GSTAMP() do { __builtin_amdgcn_s_waitcnt(0); stamp[nst++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GSTAMP() do {} while (0)
+#endif
+    GSTAMP();
     // staging coordinates: f = tid + 256 i -> row f / 16, float4 column f % 16 (2 RI float4 per thread for A, 4 for B)
     const int sr = tid >> 4, sc4 = tid & 15;
     constexpr int NRA = 2 * RI;
@@ -728,30 +766,19 @@ __device__ __forceinline__ void gemm64_body(const GemmTask& T, float* lds) {
 #pragma unroll
     for (int i = 0; i < NRA; ++i) { mean[i] = 0.f; rstd[i] = 1.f; }
     if (a_ln) {
-        const int ntin = T.i0;  // 64-column tiles of the producing layer (<= 16: widths <= 1024)
         const float inv = 1.0f / (float)T.ln_width;
-        f32x4 pv[NRA][8];
-#pragma unroll
-        for (int i = 0; i < NRA; ++i) {
-            const float* pp = T.aux2 + (size_t)(row0 + sr + 16 * i) * ((2 * ntin + 3) & ~3);  // rows padded to 16 B
-#pragma unroll
-            for (int t = 0; t < 8; ++t) pv[i][t] = ldg4(pp + 4 * min(t, (ntin - 1) >> 1));  // 2 tiles per float4, clamped
-        }
+        float sm[NRA], sq[NRA];
+        ln_fold_partials<NRA>(T.aux2, row0 + sr, T.i0, sm, sq);   // T.i0 = K / 32 partials per row
 #pragma unroll
         for (int i = 0; i < NRA; ++i) {
             const int row = row0 + sr + 16 * i;
-            float s = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                if (2 * t < ntin) { s += pv[i][t][0]; s2 += pv[i][t][1]; }
-                if (2 * t + 1 < ntin) { s += pv[i][t][2]; s2 += pv[i][t][3]; }
-            }
-            mean[i] = s * inv;
-            const float var = fmaxf(0.0f, s2 * inv - mean[i] * mean[i]);
+            mean[i] = sm[i] * inv;
+            const float var = fmaxf(0.0f, sq[i] * inv - mean[i] * mean[i]);
             rstd[i] = 1.0f / sqrtf(var + 1e-6f);
             if (ln_wr && sc4 == 0) { stg(T.ln_stats + 2 * row, mean[i]); stg(T.ln_stats + 2 * row + 1, rstd[i]); }
         }
     }
+    GSTAMP();   // [1] LayerNorm statistics folded
     f32x4 ra0[NRA], rb0[4], ra1[NRA], rb1[4];  // two register sets: a chunk's loads stay in flight across two compute phases
     const float* __restrict__ Ag = T.A + (size_t)(row0 + sr) * T.lda + 4 * sc4;
     const float* __restrict__ Bg = transb ? T.B + (size_t)(n0 + sr) * T.ldb + 4 * sc4 : T.B + (size_t)sr * T.ldb + n0 + 4 * sc4;
@@ -826,6 +853,7 @@ __device__ __forceinline__ void gemm64_body(const GemmTask& T, float* lds) {
     if (nchunks > 1) load_chunk(ra0, rb0, 64);
     if (nchunks > 2) load_chunk(ra1, rb1, 128);
     __syncthreads();
+    GSTAMP();   // [2] first chunk staged (the stamp's wait also drains the two prefetched chunks: diagnostics only)
 #ifdef FQL_STAMPS  // diagnostic ablations (never in the product build): bit 15 = no streaming loads, bit 16 = no MFMAs
     const bool dbg_noload = (flags >> 15) & 1, dbg_nocompute = (flags >> 16) & 1;
 #else
@@ -844,6 +872,7 @@ __device__ __forceinline__ void gemm64_body(const GemmTask& T, float* lds) {
         }
     }
 
+    GSTAMP();   // [3] K loop done
     // ---- epilogue. C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
     float s1[RI][4], s2[RI][4];
 #pragma unroll
@@ -881,25 +910,241 @@ __device__ __forceinline__ void gemm64_body(const GemmTask& T, float* lds) {
                 }
             }
         __syncthreads();
-        if (tid < TM) {
-            float* pp = T.aux + (size_t)(row0 + tid) * ((2 * T.i1 + 3) & ~3) + 2 * tn;
-            stg(pp, part[tid * 2] + part[(TM + tid) * 2]);
-            stg(pp + 1, part[tid * 2 + 1] + part[(TM + tid) * 2 + 1]);
+        if (tid < 2 * TM) {   // one partial per 32 columns (the column half of a wave): T.i1 = N / 32 partials per row
+            const int half = tid / TM, rl = tid - half * TM;
+            float* pp = T.aux + (size_t)(row0 + rl) * ((2 * T.i1 + 3) & ~3) + 2 * (2 * tn + half);
+            stg(pp, part[(half * TM + rl) * 2]);
+            stg(pp + 1, part[(half * TM + rl) * 2 + 1]);
         }
+    }
+#ifdef FQL_STAMPS
+    GSTAMP();   // [4] epilogue stored
+    if (tid == 0 && T.stamps64) {
+        unsigned long long* d = T.stamps64 + (size_t)blockIdx.x * 8;
+        for (int i = 0; i < nst; ++i) d[i] = stamp[i];
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Throughput-lane tile, round 2: 32 x 32 or 32 x 64 output tile (NJ = 1 | 2 MFMA column tiles per wave), K streamed through
+// LDS in 64-deep chunks exactly as above.  Why a second shape: a level of the side lane is ~1536 rows x 512 columns = 384
+// tiles of 32 x 64 on 256 CUs - half the CUs get two tiles, the level lasts two tile times; 768 tiles of 32 x 32 are three per
+// CU on every CU (three co-resident workgroups also fill each other's barrier / LDS-store bubbles).  The engine picks the shape
+// per launch from the tile count (schedule()).
+// LayerNorm on the A operand is applied when a chunk is STORED to LDS, not when it is loaded: the loads of the next two chunks
+// stay in flight across the MFMA phase (round 1 normalised at load time, which put a full L2 round trip in front of every
+// chunk's MFMAs: 22.7 against 16.2 us per level), and the first chunks are requested before the row statistics are folded.
+// LN partial sums are per 32 output columns whatever the tile shape, so producer and consumer need not agree on a shape.
+// ------------------------------------------------------------------------------------------------
+template <bool transb, int NJ>
+__device__ __forceinline__ void gemm32_body(const GemmTask& T, float* lds) {
+    constexpr int TN = 32 * NJ;
+    constexpr int BS = transb ? G64_S : TN + 4;   // LDS row stride of a B chunk: [n][k] (dgrad) or [k][n]
+    constexpr int BROWS = transb ? TN : 64;
+    constexpr int NB = 2 * NJ;                    // float4 per thread of a B chunk
+    float* As = lds;                              // [2][32][G64_S]
+    float* Bs = lds + 2 * 32 * G64_S;             // [2][BROWS][BS]
+    float* part = Bs + 2 * BROWS * BS;            // [2 column halves][32][2] LN partial sums of the epilogue
+    const int local = (int)blockIdx.x - T.tile0;
+    const int tm = local / T.ntn, tn = local - tm * T.ntn;
+    const int row0 = tm * 32, n0 = tn * TN;
+    const int K = T.K;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int c = lane & 15, q = lane >> 4;
+    const int flags = T.flags;
+    const bool a_ln = (flags & GF_A_LN) != 0;
+    const bool ln_wr = (flags & GF_LN_WRITE) && tn == 0;
+#ifdef FQL_STAMPS
+    unsigned long long stamp[8];
+    int nst = 0;
+#define TSTAMP() do { __builtin_amdgcn_s_waitcnt(0); stamp[nst++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TSTAMP() do {} while (0)
+#endif
+    TSTAMP();
+    const int sr = tid >> 4, sc4 = tid & 15;      // A staging: rows sr, sr + 16; float4 column sc4
+    // B staging coordinates of float4 i (row of the LDS image, float offset inside the row)
+    const int br0 = (transb || NJ == 2) ? sr : (tid >> 3), brs = (transb || NJ == 2) ? 16 : 32;
+    const int bc4 = (transb || NJ == 2) ? sc4 : (tid & 7);
+    const float* __restrict__ Ag = T.A + (size_t)(row0 + sr) * T.lda + 4 * sc4;
+    const float* __restrict__ Bg = transb ? T.B + (size_t)(n0 + br0) * T.ldb + 4 * bc4 : T.B + (size_t)br0 * T.ldb + n0 + 4 * bc4;
+    f32x4 ra0[2], rb0[NB], ra1[2], rb1[NB], lg0, lb0, lg1, lb1;
+    lg0 = lb0 = lg1 = lb1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto load_chunk = [&](f32x4 (&ra)[2], f32x4 (&rb)[NB], f32x4& lg, f32x4& lb, int k0) {   // K is a multiple of 64: no guards
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ra[i] = ldg4(Ag + (size_t)(16 * i) * T.lda + k0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = transb ? ldg4(Bg + (size_t)(brs * i) * T.ldb + k0) : ldg4(Bg + (size_t)(k0 + brs * i) * T.ldb);
+        if (a_ln) { lg = ldg4(T.ln_g + k0 + 4 * sc4); lb = ldg4(T.ln_b + k0 + 4 * sc4); }
+    };
+    const int nchunks = K >> 6;
+    load_chunk(ra0, rb0, lg0, lb0, 0);
+    if (nchunks > 1) load_chunk(ra1, rb1, lg1, lb1, 64);
+    float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f};
+    if (a_ln) {   // the partial sums travel behind the first two chunks; nothing waits for either before the fold below
+        const float inv = 1.0f / (float)T.ln_width;
+        float sm[2], sq[2];
+        ln_fold_partials<2>(T.aux2, row0 + sr, T.i0, sm, sq);   // T.i0 = K / 32 partials per row
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            mean[i] = sm[i] * inv;
+            const float var = fmaxf(0.0f, sq[i] * inv - mean[i] * mean[i]);
+            rstd[i] = 1.0f / sqrtf(var + 1e-6f);
+            if (ln_wr && sc4 == 0) { const int row = row0 + sr + 16 * i; stg(T.ln_stats + 2 * row, mean[i]); stg(T.ln_stats + 2 * row + 1, rstd[i]); }
+        }
+    }
+    TSTAMP();   // [1] LayerNorm statistics folded
+    auto store_chunk = [&](f32x4 (&ra)[2], const f32x4 (&rb)[NB], const f32x4& lg, const f32x4& lb, int k0, int buf) {
+        float* a = As + buf * 32 * G64_S;
+        float* b = Bs + buf * BROWS * BS;
+        if (a_ln) {   // utils/networks.py:58 on the rows of this chunk
+            const int k = k0 + 4 * sc4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = (ra[i][e] - mean[i]) * rstd[i] * lg[e] + lb[e];
+                    ra[i][e] = (k + e < T.ln_width) ? v : 0.f;
+                }
+                if (ln_wr) stg4(T.ln_xout + (size_t)(row0 + sr + 16 * i) * T.lda + k, ra[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(a + (sr + 16 * i) * G64_S + 4 * sc4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(b + (br0 + brs * i) * BS + 4 * bc4) = rb[i];
+    };
+    f32x4 acc[NJ][2];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bias[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bias[j] = (flags & GF_BIAS) ? ldg(T.bias + n0 + (wc * NJ + j) * 16 + c) : 0.f;
+
+    auto compute = [&](int buf) {
+        const float* a = As + buf * 32 * G64_S + (16 * wr + c) * G64_S + 4 * q;
+        const float* b = Bs + buf * BROWS * BS;
+        f32x4 fa[2], fb[2][NJ];   // [pipeline slot]: group g+1's fragments are read while group g multiplies
+        auto read_frags = [&](int slot, int g) {
+            fa[slot] = *reinterpret_cast<const f32x4*>(a + 16 * g);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int col = (wc * NJ + j) * 16 + c;
+                if (transb) fb[slot][j] = *reinterpret_cast<const f32x4*>(b + col * BS + 16 * g + 4 * q);
+                else {
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) fb[slot][j][s4] = b[(16 * g + 4 * q + s4) * BS + col];
+                }
+            }
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) read_frags((g + 1) & 1, g + 1);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[j][g & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[g & 1][s4], fb[g & 1][j][s4], acc[j][g & 1], 0, 0, 0);
+        }
+    };
+    // chunk ch computes from LDS slot ch & 1 while chunks ch+1 (registers) and ch+2 (in flight) follow
+    store_chunk(ra0, rb0, lg0, lb0, 0, 0);
+    if (nchunks > 2) load_chunk(ra0, rb0, lg0, lb0, 128);
+    __syncthreads();
+    TSTAMP();   // [2] first chunk staged
+    for (int ch = 0; ch < nchunks; ch += 2) {
+        compute(0);
+        if (ch + 1 < nchunks) store_chunk(ra1, rb1, lg1, lb1, 64 * (ch + 1), 1);
+        __syncthreads();
+        if (ch + 3 < nchunks) load_chunk(ra1, rb1, lg1, lb1, 64 * (ch + 3));
+        if (ch + 1 < nchunks) {
+            compute(1);
+            if (ch + 2 < nchunks) store_chunk(ra0, rb0, lg0, lb0, 64 * (ch + 2), 0);
+            __syncthreads();
+            if (ch + 4 < nchunks) load_chunk(ra0, rb0, lg0, lb0, 64 * (ch + 4));
+        }
+    }
+    TSTAMP();   // [3] K loop done
+
+    // ---- epilogue. C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
+    float s1[4], s2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = row0 + 16 * wr + 4 * q + r;
+        s1[r] = 0.f; s2[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + (wc * NJ + j) * 16 + c;
+            const size_t o = (size_t)row * T.ldc + n;
+            float v = acc[j][0][r] + acc[j][1][r] + bias[j];
+            if (flags & GF_SAVE_Z) stg(T.Zout + o, v);
+            if (flags & GF_GELU) v = gelu_f(v);
+            if (flags & GF_GELUGRAD) v *= gelu_grad_f(ldg(T.Zprev + o));
+            if (flags & GF_RELUGRAD) v = (ldg(T.Zprev + o) > 0.f) ? v : 0.f;
+            stg(T.C + o, v);
+            s1[r] += v; s2[r] += v * v;
+        }
+    }
+    if (flags & GF_LN_PART) {   // per-row (sum, sum of squares) of each 32-column half: T.i1 = N / 32 partials per row
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = s1[r], b = s2[r];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+            if (c == 0) {
+                const int rl = 16 * wr + 4 * q + r;
+                part[(wc * 32 + rl) * 2] = a;
+                part[(wc * 32 + rl) * 2 + 1] = b;
+            }
+        }
+        __syncthreads();
+        const int rs = (2 * T.i1 + 3) & ~3;
+        if (NJ == 2) {
+            if (tid < 64) {
+                const int half = tid >> 5, rl = tid & 31;
+                float* pp = T.aux + (size_t)(row0 + rl) * rs + 2 * (2 * tn + half);
+                stg(pp, part[(half * 32 + rl) * 2]);
+                stg(pp + 1, part[(half * 32 + rl) * 2 + 1]);
+            }
+        } else if (tid < 32) {
+            float* pp = T.aux + (size_t)(row0 + tid) * rs + 2 * tn;
+            stg(pp, part[tid * 2] + part[(32 + tid) * 2]);
+            stg(pp + 1, part[tid * 2 + 1] + part[(32 + tid) * 2 + 1]);
+        }
+    }
+#ifdef FQL_STAMPS
+    TSTAMP();   // [4] epilogue stored
+    if (tid == 0 && T.stamps64) {
+        unsigned long long* d = T.stamps64 + (size_t)blockIdx.x * 8;
+        for (int i = 0; i < nst; ++i) d[i] = stamp[i];
+    }
+#endif
+}
+#define FQL_TILE_LDS_FLOATS(NJ) (2 * 32 * G64_S + 2 * 64 * G64_S + 128)   /* upper bound over transb / NJ */
+
+// one throughput-lane tile task: T.tmt = 2 -> 64 x 64 tile (round-1 body; BIG launches only: it needs twice the registers, and
+// the 32-row shapes want three or four workgroups per CU), else 32 x (32 T.wk)
+template <bool BIG>
+__device__ __forceinline__ void gemm_tile_dispatch(const GemmTask& T, float* lds) {
+    if (BIG && T.tmt == 2) {
+        if (T.flags & GF_TRANS_B) gemm64_body<true, 2>(T, lds);
+        else gemm64_body<false, 2>(T, lds);
+    } else if (T.wk == 2) {
+        if (T.flags & GF_TRANS_B) gemm32_body<true, 2>(T, lds);
+        else gemm32_body<false, 2>(T, lds);
+    } else {
+        if (T.flags & GF_TRANS_B) gemm32_body<true, 1>(T, lds);
+        else gemm32_body<false, 1>(T, lds);
     }
 }
 
 __global__ __launch_bounds__(FQL_THREADS, 2) void fql_gemm64_kernel(const GemmTask* __restrict__ tasks, int ntasks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int ti = find_task(tasks, ntasks, blockIdx.x);
-    const GemmTask& T = tasks[ti];
-    if (T.tmt == 1) {
-        if (T.flags & GF_TRANS_B) gemm64_body<true, 1>(T, lds);
-        else gemm64_body<false, 1>(T, lds);
-    } else {
-        if (T.flags & GF_TRANS_B) gemm64_body<true, 2>(T, lds);
-        else gemm64_body<false, 2>(T, lds);
-    }
+    gemm_tile_dispatch<true>(tasks[ti], lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1889,20 +2134,17 @@ __global__ void fql_dataset_add_kernel(float* obs, float* act, float* rew, float
 // Every kernel boundary costs the whole chip ~3 us of launch / cache-flush time whichever stream it sits on
 // (experiments/multi_chain.hip), so independent work of one level shares a launch even across kernel families.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(FQL_THREADS, 2) void fql_side_kernel(const GemmTask* __restrict__ gt, int ngt, const WgradTask* __restrict__ wt,
+#ifndef FQL_SIDE_WAVES
+#define FQL_SIDE_WAVES 3
+#endif
+template <bool BIG>   // BIG: the launch contains 64 x 64 tile tasks (batches >= 1024)
+__global__ __launch_bounds__(FQL_THREADS, BIG ? 2 : FQL_SIDE_WAVES) void fql_side_kernel(const GemmTask* __restrict__ gt, int ngt, const WgradTask* __restrict__ wt,
                                                                   int nwt, const LnBwdTask* __restrict__ lt, int nlt, int tile_w, int tile_l,
                                                                   const MiscTask* __restrict__ mt, int tile_m) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x;
     if (b < tile_w) {
-        const GemmTask& T = gt[find_task(gt, ngt, b)];
-        if (T.tmt == 1) {
-            if (T.flags & GF_TRANS_B) gemm64_body<true, 1>(T, lds);
-            else gemm64_body<false, 1>(T, lds);
-        } else {
-            if (T.flags & GF_TRANS_B) gemm64_body<true, 2>(T, lds);
-            else gemm64_body<false, 2>(T, lds);
-        }
+        gemm_tile_dispatch<BIG>(gt[find_task(gt, ngt, b)], lds);
     } else if (b < tile_l) {
         const int bid = b - tile_w;
         wgrad_body(wt[find_task(wt, nwt, bid)], bid, lds);
