@@ -62,14 +62,14 @@ int main(int argc, char** argv) {
         const size_t lds = ((size_t)16 * (H + 4) + 1024 + 1280) * 4;
         hipGraph_t g; hipGraphExec_t ge;
         CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        for (int i = 0; i < 96; ++i) hipLaunchKernelGGL((fql_gemm16_kernel<false, false>), dim3(grid), dim3(256), lds, s, tb + (i % 8), 1);
+        for (int i = 0; i < 96; ++i) hipLaunchKernelGGL((fql_gemm16_kernel<false, false>), dim3(grid), dim3(256), lds, s, tb + (i % 8), 1, -1);
         CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         printf("old gemm16 layer (256 threads, row-major W, table task): %.2f us per launch\n", time_graph(s, ge, 96));
     }
     auto base = [&](int i) {
         ChainArgs a{};
         a.A = (i & 1) ? A1 : A0; a.C = (i & 1) ? A0 : A1; a.Wf = Wf + (size_t)(i % 8) * H * H; a.bias = b;
-        a.M = M; a.ad = ad; a.ap = ap; a.inv_steps = 0.1f; a.t_s = 0.3f; a.variant = 1;
+        a.M = M; a.ad = ad; a.ap = ap; a.inv_steps = 0.1f; a.t_s = 0.3f; a.variant = 1; a.tl = -1;
 #ifdef FQL_STAMPS
         a.stamps = stamps;
 #endif

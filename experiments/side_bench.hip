@@ -2,7 +2,7 @@
 // on 768 rows plus three 256-row passes, [M x 512] x [512 x 512] each = 384 tiles of 32 x 64.  48 launches per hipGraph.
 // Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -o experiments/side_bench experiments/side_bench.hip
 //         (-DFQL_STAMPS: in-kernel phase stamps; never quote that build's run time)
-// argv: [1] flags preset: 0 = bias+gelu+save_z, 1 = + LayerNorm on A and LN partials out (critic layers)   [2] tile: 1 = 32x32, 2 = 32x64, 4 = 64x64
+// argv: [1] flags preset: 0 = bias+gelu+save_z, 1 = + LayerNorm on A and LN partials out (critic layers), 2 = dgrad (W^T) of 4 x 256 rows   [2] tile: 1 = 32x32, 2 = 32x64, 4 = 64x64
 #include "../fql_amd/csrc/fql_kernels.h"
 #include <algorithm>
 #include <chrono>
@@ -14,13 +14,14 @@ int main(int argc, char** argv) {
     const int preset = argc > 1 ? atoi(argv[1]) : 0, shape = argc > 2 ? atoi(argv[2]) : 2;
     const int RI = shape == 4 ? 2 : 1, NJ = shape == 1 ? 1 : 2;
     const int N = 512, K = 512;
-    const int Ms[4] = {768, 256, 256, 256};
+    const int Ms[4] = {preset >= 2 ? 256 : 768, 256, 256, 256};
     int flags = GF_BIAS | GF_GELU | GF_SAVE_Z;
     if (preset == 1) flags |= GF_A_LN | GF_LN_WRITE | GF_LN_PART;
+    if (preset == 2) flags = GF_TRANS_B;
     hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    const size_t rows = 768 + 3 * 256;
-    float *A0, *A1, *Z, *XN, *W, *b, *part, *stats;
-    CK(hipMalloc(&A0, rows * 512 * 4)); CK(hipMalloc(&A1, rows * 512 * 4)); CK(hipMalloc(&Z, rows * 512 * 4)); CK(hipMalloc(&XN, rows * 512 * 4));
+    const size_t rows = Ms[0] + 3 * 256;
+    float *A0, *A1, *Z, *Z2, *XN, *W, *b, *part, *stats;
+    CK(hipMalloc(&A0, rows * 512 * 4)); CK(hipMalloc(&A1, rows * 512 * 4)); CK(hipMalloc(&Z, rows * 512 * 4)); CK(hipMalloc(&Z2, rows * 512 * 4)); CK(hipMalloc(&XN, rows * 512 * 4));
     CK(hipMalloc(&W, (size_t)4 * K * N * 4)); CK(hipMalloc(&b, 4096 * 4)); CK(hipMalloc(&part, rows * 32 * 4)); CK(hipMalloc(&stats, rows * 2 * 4));
     std::vector<float> hw((size_t)4 * K * N), ha(rows * 512);
     for (size_t i = 0; i < hw.size(); ++i) hw[i] = ((float)((i * 2654435761u) >> 8 & 0xFFFF) / 65536.0f - 0.5f) * 0.08f;
@@ -29,7 +30,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(A0, ha.data(), ha.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(A1, ha.data(), ha.size() * 4, hipMemcpyHostToDevice));
     std::vector<float> ones(4096, 1.0f);
     CK(hipMemcpy(b, ones.data(), 4096 * 4, hipMemcpyHostToDevice));
-    CK(hipMemset(part, 0, rows * 32 * 4));
+    CK(hipMemset(part, 0, rows * 32 * 4)); CK(hipMemset(stats, 0, rows * 2 * 4)); CK(hipMemcpy(Z, ha.data(), rows * 512 * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(XN, ha.data(), rows * 512 * 4, hipMemcpyHostToDevice));
     unsigned long long* stamps; CK(hipMalloc(&stamps, 8 * 4096 * 8)); CK(hipMemset(stamps, 0, 8 * 4096 * 8));
     GemmTask* tb; CK(hipMalloc(&tb, 8 * sizeof(GemmTask)));
     std::vector<GemmTask> h(8);
@@ -58,10 +59,10 @@ int main(int argc, char** argv) {
     hipGraph_t g; hipGraphExec_t ge;
     CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     for (int i = 0; i < 48; ++i)
-        if (shape == 4) hipLaunchKernelGGL((fql_side_kernel<true>), dim3(grid), dim3(256), lds, s, (const GemmTask*)(tb + (i % 2) * 4), 4, (const WgradTask*)nullptr, 0,
-                           (const LnBwdTask*)nullptr, 0, grid, grid, (const MiscTask*)nullptr, grid);
-        else hipLaunchKernelGGL((fql_side_kernel<false>), dim3(grid), dim3(256), lds, s, (const GemmTask*)(tb + (i % 2) * 4), 4, (const WgradTask*)nullptr, 0,
-                           (const LnBwdTask*)nullptr, 0, grid, grid, (const MiscTask*)nullptr, grid);
+        if (shape == 4) hipLaunchKernelGGL(fql_side_big_kernel, dim3(grid), dim3(256), lds, s, (const GemmTask*)(tb + (i % 2) * 4), 4, (const WgradTask*)nullptr, 0,
+                           (const LnBwdTask*)nullptr, 0, grid, grid, (const MiscTask*)nullptr, grid, 0, -1);
+        else hipLaunchKernelGGL(fql_side_kernel, dim3(grid), dim3(256), lds, s, (const GemmTask*)(tb + (i % 2) * 4), 4, (const WgradTask*)nullptr, 0,
+                           (const LnBwdTask*)nullptr, 0, grid, grid, (const MiscTask*)nullptr, grid, 0, -1);
     CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
     for (int i = 0; i < 10; ++i) CK(hipGraphLaunch(ge, s));
     CK(hipStreamSynchronize(s));

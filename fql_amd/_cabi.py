@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libfql_amd.so')
+LIB_PATH = os.environ.get('FQL_AMD_LIB') or os.path.join(_HERE, 'libfql_amd.so')   # (override: kernel-variant builds under experiments/)
 
 FQL_MAX_HIDDEN = 8
 FQL_NUM_INFO = 13

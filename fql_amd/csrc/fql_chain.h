@@ -43,6 +43,7 @@ struct ChainArgs {
     int M, ad, ap, ea_ld;
     float inv_steps, t_s;
     int variant;          // 0 = A, 1 = B, 2 = C
+    int tl;               // timeline id (diagnostics build)
     int prio;             // s_setprio level of the chain's waves (they are latency-critical and light: 0.85 us of MFMA per launch)
     unsigned long long* stamps;   // diagnostics build only (FQL_STAMPS): [grid][8] wall-clock stamps
 };
@@ -55,7 +56,8 @@ struct WfragTask {
     int kvalid;       // rows [kvalid, K) are written as zeros (the rank-update block may run past the layer's padded input rows)
     int tile0;        // first workgroup of this task
 };
-__global__ __launch_bounds__(FQL_THREADS) void fql_wfrag_kernel(const WfragTask* __restrict__ tasks, int ntasks) {
+__global__ __launch_bounds__(FQL_THREADS) void fql_wfrag_kernel(const WfragTask* __restrict__ tasks, int ntasks, int tl) {
+    tl_enter(tl);
     const WfragTask& T = tasks[find_task(tasks, ntasks, blockIdx.x)];
     const int e = (blockIdx.x - T.tile0) * FQL_THREADS + threadIdx.x;   // one (k4, n) per thread
     const int n = e % T.N, k4 = e / T.N;
@@ -84,6 +86,7 @@ __global__ __launch_bounds__(FQL_CHAIN_THREADS) void fql_chain_kernel(const Chai
     const int tm = blockIdx.x / NT, tn = blockIdx.x - tm * NT;
     const int row0 = tm * 16, n0 = tn * 32 + nt * 16;
     const int variant = P.variant;
+    tl_enter(P.tl);
     if (P.prio == 3) __builtin_amdgcn_s_setprio(3);
     else if (P.prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (P.prio == 1) __builtin_amdgcn_s_setprio(1);
@@ -213,6 +216,7 @@ __global__ __launch_bounds__(FQL_CHAIN_THREADS) void fql_chain_kernel(const Chai
             }
         }
     }
+    tl_exit(P.tl);
 #ifdef FQL_STAMPS
     CSTAMP();
     if (lane == 0 && wave == 0 && P.stamps) {

@@ -443,7 +443,7 @@ struct fql_engine {
     // after any out-of-graph parameter write (init, fql_set_param): bring the copies up to date
     void refresh_chain_weights(hipStream_t s) {
         if (!use_chain) return;
-        hipLaunchKernelGGL(fql_wfrag_kernel, dim3(wfrag_grid), dim3(FQL_THREADS), 0, s, (const WfragTask*)d_wfrag, wfrag_n);
+        hipLaunchKernelGGL(fql_wfrag_kernel, dim3(wfrag_grid), dim3(FQL_THREADS), 0, s, (const WfragTask*)d_wfrag, wfrag_n, -1);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(s));
     }
@@ -1185,13 +1185,14 @@ struct fql_engine {
                 q.dY = nullptr;
                 q.dq = dz; q.ldq = ly.out_p; q.wq = P + ly.w; q.ldw = ly.out_p;
                 q.Z = rows(p.z[l - 1], prev.out_p);
+                q.Gv = rows(p.g[l - 1], prev.out_p);
                 q.stats = p.stats[l - 1] + (size_t)row_off * 2;
                 q.gamma = P + prev.g;
                 q.dZ = p.dz[l - 1];
                 q.dgamma = param_grads ? G + prev.g : nullptr;
                 q.dbeta = param_grads ? G + prev.be : nullptr;
                 q.M = M; q.H = prev.out_p; q.ld = prev.out_p; q.width = prev.out;
-                lo.reads = {dz, p.z[l - 1], p.stats[l - 1], q.gamma};
+                lo.reads = {dz, p.z[l - 1], p.g[l - 1], p.stats[l - 1], q.gamma};
                 lo.writes = {q.dZ};
                 if (param_grads) { lo.writes.push_back(q.dgamma); lo.writes.push_back(q.dbeta); }
                 push(pr, lo);
@@ -1224,13 +1225,14 @@ struct fql_engine {
                 LnBwdTask& q = lo.ln;
                 q.dY = p.dy[l - 1];
                 q.Z = rows(p.z[l - 1], prev.out_p);
+                q.Gv = rows(p.g[l - 1], prev.out_p);
                 q.stats = p.stats[l - 1] + (size_t)row_off * 2;
                 q.gamma = P + prev.g;
                 q.dZ = p.dz[l - 1];
                 q.dgamma = param_grads ? G + prev.g : nullptr;
                 q.dbeta = param_grads ? G + prev.be : nullptr;
                 q.M = M; q.H = prev.out_p; q.ld = prev.out_p; q.width = prev.out;
-                lo.reads = {q.dY, p.z[l - 1], p.stats[l - 1], q.gamma};
+                lo.reads = {q.dY, p.z[l - 1], p.g[l - 1], p.stats[l - 1], q.gamma};
                 lo.writes = {q.dZ};
                 if (param_grads) { lo.writes.push_back(q.dgamma); lo.writes.push_back(q.dbeta); }
                 push(pr, lo);
@@ -1609,24 +1611,26 @@ struct fql_engine {
             if (trace_l) fprintf(stderr, "[fql] launch %d type %d lane %d waits %zu\n", (int)(&L - pr.launches.data()), (int)L.type, L.lane, L.waits.size());
             if (par)
                 for (int w : L.waits) if (pr.launches[w].ev) HIP_CHECK(hipStreamWaitEvent(s, pr.launches[w].ev, 0));
+            static const int side_prio = getenv("FQL_SIDE_PRIO") ? atoi(getenv("FQL_SIDE_PRIO")) : 0;
+            const int tl = (&pr == &prog_full) ? (int)(&L - pr.launches.data()) : -1;   // timeline id (diagnostics build)
             switch (L.type) {
                 case OP_GEMM:
-                    if (L.euler && L.kbig) hipLaunchKernelGGL((fql_gemm16_euler_kernel<true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
-                    else if (L.euler) hipLaunchKernelGGL((fql_gemm16_euler_kernel<false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
-                    else if (L.tmt2 && L.kbig) hipLaunchKernelGGL((fql_gemm16_kernel<true, true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
-                    else if (L.tmt2) hipLaunchKernelGGL((fql_gemm16_kernel<true, false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
-                    else if (L.kbig) hipLaunchKernelGGL((fql_gemm16_kernel<false, true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
-                    else hipLaunchKernelGGL((fql_gemm16_kernel<false, false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
+                    if (L.euler && L.kbig) hipLaunchKernelGGL((fql_gemm16_euler_kernel<true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
+                    else if (L.euler) hipLaunchKernelGGL((fql_gemm16_euler_kernel<false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
+                    else if (L.tmt2 && L.kbig) hipLaunchKernelGGL((fql_gemm16_kernel<true, true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
+                    else if (L.tmt2) hipLaunchKernelGGL((fql_gemm16_kernel<true, false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
+                    else if (L.kbig) hipLaunchKernelGGL((fql_gemm16_kernel<false, true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
+                    else hipLaunchKernelGGL((fql_gemm16_kernel<false, false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
                     break;
                 case OP_GEMM64:
                     if (L.side && L.tmt2)
-                        hipLaunchKernelGGL((fql_side_kernel<true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks,
+                        hipLaunchKernelGGL(fql_side_big_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks,
                                            (const WgradTask*)L.table_w, L.n_w, (const LnBwdTask*)L.table_l, L.n_l, L.tile_w, L.tile_l,
-                                           (const MiscTask*)L.table_m, L.tile_m);
+                                           (const MiscTask*)L.table_m, L.tile_m, 0, tl);
                     else if (L.side)
-                        hipLaunchKernelGGL((fql_side_kernel<false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks,
+                        hipLaunchKernelGGL(fql_side_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks,
                                            (const WgradTask*)L.table_w, L.n_w, (const LnBwdTask*)L.table_l, L.n_l, L.tile_w, L.tile_l,
-                                           (const MiscTask*)L.table_m, L.tile_m);
+                                           (const MiscTask*)L.table_m, L.tile_m, side_prio, tl);
                     else
                         hipLaunchKernelGGL(fql_gemm64_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
                     break;
@@ -1637,7 +1641,7 @@ struct fql_engine {
                     hipLaunchKernelGGL(fql_lnbwd_kernel, dim3(L.grid), dim3(FQL_THREADS), 0, s, (const LnBwdTask*)L.table, L.ntasks);
                     break;
                 case OP_PREP:
-                    hipLaunchKernelGGL(fql_prep_kernel, dim3((L.op.prep.B + 3) / 4), dim3(FQL_THREADS), 0, s, L.op.prep);
+                    { PrepArgs pa = L.op.prep; pa.tl = tl; hipLaunchKernelGGL(fql_prep_kernel, dim3((pa.B + 3) / 4), dim3(FQL_THREADS), 0, s, pa); }
                     break;
                 case OP_POSTOS:
                     hipLaunchKernelGGL(fql_post_onestep_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.postos);
@@ -1697,21 +1701,23 @@ struct fql_engine {
                     hipLaunchKernelGGL(fql_enc_dz_kernel, dim3((a.M * a.n + FQL_THREADS - 1) / FQL_THREADS), dim3(FQL_THREADS), 0, s, a);
                     break;
                 }
-                case OP_CHAIN:
-                    if (cfg.actor_hidden[0] == 512) hipLaunchKernelGGL((fql_chain_kernel<512>), dim3((L.op.chain.M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, L.op.chain);
-                    else hipLaunchKernelGGL((fql_chain_kernel<256>), dim3((L.op.chain.M / 16) * 8), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(256), s, L.op.chain);
+                case OP_CHAIN: {
+                    ChainArgs ca = L.op.chain; ca.tl = tl;
+                    if (cfg.actor_hidden[0] == 512) hipLaunchKernelGGL((fql_chain_kernel<512>), dim3((L.op.chain.M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, ca);
+                    else hipLaunchKernelGGL((fql_chain_kernel<256>), dim3((L.op.chain.M / 16) * 8), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(256), s, ca);
                     break;
+                }
                 case OP_WFRAG:
-                    hipLaunchKernelGGL(fql_wfrag_kernel, dim3(wfrag_grid), dim3(FQL_THREADS), 0, s, (const WfragTask*)d_wfrag, wfrag_n);
+                    hipLaunchKernelGGL(fql_wfrag_kernel, dim3(wfrag_grid), dim3(FQL_THREADS), 0, s, (const WfragTask*)d_wfrag, wfrag_n, tl);
                     break;
                 case OP_ADAM: {
-                    AdamArgs a{P, G, Mu, Nu, P + n_train, d_chunks, d_state, d_partials, L.op.adam_c0, (int)critic_size, cfg.lr, cfg.tau};
+                    AdamArgs a{P, G, Mu, Nu, P + n_train, d_chunks, d_state, d_partials, L.op.adam_c0, (int)critic_size, cfg.lr, cfg.tau, tl};
                     hipLaunchKernelGGL(fql_adam_kernel, dim3(L.op.adam_n < 0 ? n_chunks : L.op.adam_n), dim3(FQL_THREADS), 0, s, a);
                     break;
                 }
                 case OP_FINALIZE:
                     hipLaunchKernelGGL(fql_finalize_kernel, dim3(1), dim3(FQL_THREADS), 0, s,
-                                       FinalizeArgs{d_state, d_chunks, d_partials, d_leaf_range, n_chunks, n_train_leaves, L.op.fin_mode});
+                                       FinalizeArgs{d_state, d_chunks, d_partials, d_leaf_range, n_chunks, n_train_leaves, L.op.fin_mode, tl});
                     break;
             }
             if (par && L.record_after) {
@@ -2898,6 +2904,46 @@ int fql_stats(fql_handle h, int64_t* launches_per_update, int64_t* macs_per_upda
 void* fql_stream(fql_handle h) { return h ? (void*)h->stream : nullptr; }
 
 }  // extern "C"
+
+// Diagnostic only (not in include/fql_amd.h), -DFQL_TIMELINE builds: per launch of the single-graph update (prog_full) lane, op type,
+// grid and the device wall-clock times (us, relative to the first entry) of its first / last workgroup entry and last exit.
+// reset = 1 clears the table (call before the update to be examined).  Returns the number of launches, or < 0.
+extern "C" int fql_debug_timeline(fql_handle h, int reset, int cap, int* lane, int* type, int* grid, double* t_first, double* t_last, double* t_exit) {
+#ifdef FQL_TIMELINE
+    if (!h) return FQL_E_INVALID;
+    hipDeviceSynchronize();
+    static std::vector<unsigned long long> host((size_t)FQL_TL_MAX * FQL_TL_WGS * 2);
+    if (reset) {
+        std::fill(host.begin(), host.end(), 0ull);
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_fql_tl), host.data(), host.size() * 8) == hipSuccess ? 0 : FQL_E_HIP;
+    }
+    if (hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(g_fql_tl), host.size() * 8) != hipSuccess) return FQL_E_HIP;
+    const int n = std::min<int>((int)h->prog_full.launches.size(), std::min(cap, FQL_TL_MAX));
+    unsigned long long t0 = ~0ull;
+    std::vector<unsigned long long> a(n, ~0ull), b(n, 0), c(n, 0);
+    for (int i = 0; i < n; ++i) {
+        grid[i] = 0;
+        for (int w = 0; w < FQL_TL_WGS; ++w) {
+            const unsigned long long e = host[((size_t)i * FQL_TL_WGS + w) * 2], x = host[((size_t)i * FQL_TL_WGS + w) * 2 + 1];
+            if (!e) continue;
+            grid[i]++;
+            a[i] = std::min(a[i], e); b[i] = std::max(b[i], e); c[i] = std::max(c[i], x);
+        }
+        if (grid[i]) t0 = std::min(t0, a[i]);
+    }
+    for (int i = 0; i < n; ++i) {
+        const Launch& L = h->prog_full.launches[i];
+        lane[i] = L.lane; type[i] = (int)L.type;
+        t_first[i] = grid[i] ? (double)(a[i] - t0) / 100.0 : -1.0;
+        t_last[i] = grid[i] ? (double)(b[i] - t0) / 100.0 : -1.0;
+        t_exit[i] = c[i] ? (double)(c[i] - t0) / 100.0 : -1.0;
+    }
+    return n;
+#else
+    (void)h; (void)reset; (void)cap; (void)lane; (void)type; (void)grid; (void)t_first; (void)t_last; (void)t_exit;
+    return FQL_E_STATE;
+#endif
+}
 
 // Diagnostic only (not in include/fql_amd.h): copy an encoder-pass buffer to the host.  enc: 0 critic, 1 bc_flow, 2 onestep, 3 target;
 // code: 100 s + {0: c0, 1: pool, 2: c1[0], 3: y[0], 4: arg (bytes)}, 900: frelu, 901: z, 902: E, 903: dz, 904: dA, 905: dB, 906: dC

@@ -23,6 +23,24 @@ __device__ __forceinline__ void stg4(float* p, f32x4 v) { *(FQL_GAS f32x4*)p = v
 
 #define FQL_THREADS 256
 
+// Diagnostics build (-DFQL_TIMELINE): every instrumented launch records the wall-clock (100 MHz) time of its first and last
+// workgroup entry and of its last exit, so the REAL overlapped schedule of the two lanes can be read back (rocprofv3 serialises
+// the graph's branches).  In the product build the marks compile to nothing; the launch id argument stays for one code path.
+#ifdef FQL_TIMELINE
+#define FQL_TL_MAX 128       // launches
+#define FQL_TL_WGS 2048      // workgroups per launch (those beyond are not recorded)
+__device__ unsigned long long g_fql_tl[FQL_TL_MAX][FQL_TL_WGS][2];   // [launch id][workgroup]: entry, exit (own slot: plain stores, no atomics)
+__device__ __forceinline__ void tl_enter(int id) {
+    if (id >= 0 && id < FQL_TL_MAX && threadIdx.x == 0 && blockIdx.x < FQL_TL_WGS) g_fql_tl[id][blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
+}
+__device__ __forceinline__ void tl_exit(int id) {
+    if (id >= 0 && id < FQL_TL_MAX && threadIdx.x == 0 && blockIdx.x < FQL_TL_WGS) g_fql_tl[id][blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+}
+#else
+#define tl_enter(id) ((void)0)
+#define tl_exit(id) ((void)0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // task descriptors (built once on the host, read from HBM by every workgroup of a launch)
 // ------------------------------------------------------------------------------------------------
@@ -30,10 +48,11 @@ enum : int {
     GF_TRANS_B = 1 << 0,    // B operand is W^T (dgrad):   C = A * W^T,  W stored [K_out=N][..]
     GF_BIAS = 1 << 1,       // + bias[n]
     GF_GELU = 1 << 2,       // GELU-tanh epilogue                      utils/networks.py:46,56
-    GF_SAVE_Z = 1 << 3,     // store the pre-activation (needed by GELU' in backward)
+    GF_SAVE_Z = 1 << 3,     // store GELU'(pre-activation) beside the GELU output: the backward pass then needs no transcendental
+                            // (LayerNorm backward reads g and g', the un-normalised dgrad epilogue multiplies by g')
     GF_A_LN = 1 << 4,       // LayerNorm the A tile in LDS before the product   utils/networks.py:58
     GF_LN_WRITE = 1 << 5,   // column-tile 0 also stores LN(A) and (mean, rstd) for backward
-    GF_GELUGRAD = 1 << 6,   // epilogue: C = acc * GELU'(Zprev)  (dgrad through an un-normalised layer)
+    GF_GELUGRAD = 1 << 6,   // epilogue: C = acc * Zprev, Zprev = the stored GELU'(z)  (dgrad through an un-normalised layer)
     GF_EULER = 1 << 7,      // epilogue: a += v / flow_steps, t column := t_next    agents/fql.py:166-169
     GF_EULER_LAST = 1 << 8, // ... and store clip(a, -1, 1) as the distillation target  agents/fql.py:170
     GF_CLIP_OUT = 1 << 9,   // epilogue: C = clip(acc + bias, -1, 1)            agents/fql.py:152
@@ -52,8 +71,8 @@ struct GemmTask {
     const float* B;     // W: [K, N] ldb (or [N.., K..] read transposed with GF_TRANS_B)
     const float* bias;  // [N]
     float* C;           // [M, N] ldc
-    float* Zout;        // [M, N] ldc   (GF_SAVE_Z)
-    const float* Zprev; // [M, N] ldc   (GF_GELUGRAD)
+    float* Zout;        // [M, N] ldc   (GF_SAVE_Z): GELU'(z)
+    const float* Zprev; // [M, N] ldc   (GF_GELUGRAD: stored GELU'(z) of the previous layer; GF_RELUGRAD: its output)
     const float* ln_g;  // [K]          (GF_A_LN)
     const float* ln_b;  // [K]
     float* ln_xout;     // [M, K] lda   (GF_LN_WRITE)
@@ -95,7 +114,8 @@ struct WgradTask {
 
 struct LnBwdTask {
     const float* dY;     // [M, H] ld   gradient w.r.t. LN output
-    const float* Z;      // [M, H] ld   pre-activation of the layer (g = gelu(z) is what LN normalised)
+    const float* Z;      // [M, H] ld   GELU'(z) of the layer as stored by the forward pass
+    const float* Gv;     // [M, H] ld   GELU(z) = what the LayerNorm normalised
     const float* stats;  // [M, 2] mean, rstd
     const float* gamma;  // [H]
     float* dZ;           // [M, H] ld   out: gradient w.r.t. the pre-activation
@@ -157,6 +177,20 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return r * fmaf(x * (e * r), fmaf(0.2140644f, x2, 1.5957691216f), 1.0f);
 }
 #endif
+__device__ __forceinline__ void gelu_both(float x, float& g, float& dg) {
+#ifdef FQL_GELU_TANH
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    const float th = fast_tanh(u);
+    const float du = 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
+    g = 0.5f * x * (1.0f + th);
+    dg = 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * du;
+#else
+    float r, e, x2;
+    gelu_core(x, r, e, x2);
+    g = x * r;
+    dg = r * fmaf(x * (e * r), fmaf(0.2140644f, x2, 1.5957691216f), 1.0f);
+#endif
+}
 __device__ __forceinline__ float clip1(float x) { return fminf(fmaxf(x, -1.0f), 1.0f); }
 
 // Philox4x32-10 (Salmon et al. 2011), counter-based: the engine's own RNG stream (the reference's
@@ -642,9 +676,9 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
             if (n == 0) stg(xr + T.i2, T.f1);
             continue;
         }
-        if (flags & GF_SAVE_Z) stg(T.Zout + o, v);
-        if (flags & GF_GELU) v = gelu_f(v);
-        if (flags & GF_GELUGRAD) v *= gelu_grad_f(zpre[rt][i]);
+        if (flags & GF_SAVE_Z) { float gg, dg; gelu_both(v, gg, dg); stg(T.Zout + o, dg); v = (flags & GF_GELU) ? gg : v; }
+        else if (flags & GF_GELU) v = gelu_f(v);
+        if (flags & GF_GELUGRAD) v *= zpre[rt][i];
         if (flags & GF_RELUGRAD) v = (zpre[rt][i] > 0.f) ? v : 0.f;
         if (flags & GF_CLIP_OUT) v = clip1(v);
         stg(T.C + o, v);
@@ -673,8 +707,9 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
 // (Passing the task by value in the kernel-argument segment was tried for single-task launches: slower -- the
 // kernarg segment is host-visible memory and a 200-byte struct costs more than one hop through the HBM table.)
 template <bool TMT2, bool KBIG>
-__global__ __launch_bounds__(FQL_THREADS, FQL_GEMM_WAVES) void fql_gemm16_kernel(const GemmTask* __restrict__ tasks, int ntasks) {
+__global__ __launch_bounds__(FQL_THREADS, FQL_GEMM_WAVES) void fql_gemm16_kernel(const GemmTask* __restrict__ tasks, int ntasks, int tl) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    tl_enter(tl);
     const GemmTask& T = tasks[find_task(tasks, ntasks, blockIdx.x)];
     if (TMT2 && T.tmt == 2) {
         if (T.K <= 128) gemm16_body<2, 2, false>(T, lds);
@@ -685,15 +720,18 @@ __global__ __launch_bounds__(FQL_THREADS, FQL_GEMM_WAVES) void fql_gemm16_kernel
         else if (!KBIG || T.K <= 512) gemm16_body<8, 1, false>(T, lds);
         else gemm16_body<16, 1, false>(T, lds);
     }
+    tl_exit(tl);
 }
 // Euler-chain launches (fused layer-0 build / head partial): own kernel so their registers do not tax the others
 template <bool KBIG>
-__global__ __launch_bounds__(FQL_THREADS) void fql_gemm16_euler_kernel(const GemmTask* __restrict__ tasks, int ntasks) {
+__global__ __launch_bounds__(FQL_THREADS) void fql_gemm16_euler_kernel(const GemmTask* __restrict__ tasks, int ntasks, int tl) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    tl_enter(tl);
     const GemmTask& T = tasks[find_task(tasks, ntasks, blockIdx.x)];
     if (T.K <= 128) gemm16_body<2, 1, true>(T, lds);
     else if (!KBIG || T.K <= 512) gemm16_body<8, 1, true>(T, lds);
     else gemm16_body<16, 1, true>(T, lds);
+    tl_exit(tl);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -707,34 +745,34 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_gemm16_euler_kernel(const Gem
 // ------------------------------------------------------------------------------------------------
 #define G64_S 68  // LDS row stride (floats): 64 + 4, keeps 16-byte alignment and spreads banks
 // Fold the per-32-column LayerNorm partial sums (sum, sum of squares) of NR rows (row_first + 16 i) in fixed order: 2 partials per
-// float4, batches of 8 float4 per row (a second batch only for widths above 512), rows padded to 16 bytes.
+// float4, batches of 4 float4 per row (two batches at width 512: the batch size bounds the live registers), rows padded to 16 bytes.
 template <int NR>
 __device__ __forceinline__ void ln_fold_partials(const float* __restrict__ partials, int row_first, int ntin, float (&sum)[NR], float (&sumsq)[NR]) {
     const int rs = (2 * ntin + 3) & ~3;
     const int nf4 = (ntin + 1) >> 1;
 #pragma unroll
     for (int i = 0; i < NR; ++i) { sum[i] = 0.f; sumsq[i] = 0.f; }
-    for (int base = 0; base < nf4; base += 8) {   // uniform trip count (1 for widths <= 512)
-        f32x4 pv[NR][8];
+    for (int base = 0; base < nf4; base += 4) {   // uniform trip count
+        f32x4 pv[NR][4];
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const float* pp = partials + (size_t)(row_first + 16 * i) * rs;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) pv[i][t] = ldg4(pp + 4 * min(base + t, nf4 - 1));
+            for (int t = 0; t < 4; ++t) pv[i][t] = ldg4(pp + 4 * min(base + t, nf4 - 1));
         }
 #pragma unroll
         for (int i = 0; i < NR; ++i)
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
+            for (int t = 0; t < 4; ++t) {
                 if (2 * (base + t) < ntin) { sum[i] += pv[i][t][0]; sumsq[i] += pv[i][t][1]; }
                 if (2 * (base + t) + 1 < ntin) { sum[i] += pv[i][t][2]; sumsq[i] += pv[i][t][3]; }
             }
     }
 }
 
-
-// RI = 16-row MFMA tiles per wave along M: 2 -> 64 x 64 workgroup tile, 1 -> 32 x 64 (half the serial MFMA time per
-// workgroup and twice the workgroups: the side lane's levels are latency chains too, so the smaller tile wins there)
+// ------------------------------------------------------------------------------------------------
+// Throughput lane GEMM, 64 x 64 tile (batches >= 1024); see the header comment above
+// ------------------------------------------------------------------------------------------------
 template <bool transb, int RI>
 __device__ __forceinline__ void gemm64_body(const GemmTask& T, float* lds) {
     constexpr int TM = 32 * RI;
@@ -886,9 +924,9 @@ __device__ __forceinline__ void gemm64_body(const GemmTask& T, float* lds) {
                 const int n = n0 + 32 * wc + 16 * j + c;
                 const size_t o = (size_t)row * T.ldc + n;
                 float v = acc[i][j][r] + (j ? bias1 : bias0);
-                if (flags & GF_SAVE_Z) stg(T.Zout + o, v);
-                if (flags & GF_GELU) v = gelu_f(v);
-                if (flags & GF_GELUGRAD) v *= gelu_grad_f(ldg(T.Zprev + o));
+                if (flags & GF_SAVE_Z) { float gg, dg; gelu_both(v, gg, dg); stg(T.Zout + o, dg); v = (flags & GF_GELU) ? gg : v; }
+                else if (flags & GF_GELU) v = gelu_f(v);
+                if (flags & GF_GELUGRAD) v *= ldg(T.Zprev + o);
                 if (flags & GF_RELUGRAD) v = (ldg(T.Zprev + o) > 0.f) ? v : 0.f;
                 stg(T.C + o, v);
                 s1[i][r] += v; s2[i][r] += v * v;
@@ -1080,9 +1118,9 @@ __device__ __forceinline__ void gemm32_body(const GemmTask& T, float* lds) {
             const int n = n0 + (wc * NJ + j) * 16 + c;
             const size_t o = (size_t)row * T.ldc + n;
             float v = acc[j][0][r] + acc[j][1][r] + bias[j];
-            if (flags & GF_SAVE_Z) stg(T.Zout + o, v);
-            if (flags & GF_GELU) v = gelu_f(v);
-            if (flags & GF_GELUGRAD) v *= gelu_grad_f(ldg(T.Zprev + o));
+            if (flags & GF_SAVE_Z) { float gg, dg; gelu_both(v, gg, dg); stg(T.Zout + o, dg); v = (flags & GF_GELU) ? gg : v; }
+            else if (flags & GF_GELU) v = gelu_f(v);
+            if (flags & GF_GELUGRAD) v *= ldg(T.Zprev + o);
             if (flags & GF_RELUGRAD) v = (ldg(T.Zprev + o) > 0.f) ? v : 0.f;
             stg(T.C + o, v);
             s1[r] += v; s2[r] += v * v;
@@ -1236,20 +1274,6 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_wgrad_kernel(const WgradTask*
 // (param grads): dgamma = sum_m dY xhat, dbeta = sum_m dY; one workgroup per 16 columns, 16 row
 // groups per workgroup, fixed summation order (deterministic).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void gelu_both(float x, float& g, float& dg) {
-#ifdef FQL_GELU_TANH
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    const float th = fast_tanh(u);
-    const float du = 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
-    g = 0.5f * x * (1.0f + th);
-    dg = 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * du;
-#else
-    float r, e, x2;
-    gelu_core(x, r, e, x2);
-    g = x * r;
-    dg = r * fmaf(x * (e * r), fmaf(0.2140644f, x2, 1.5957691216f), 1.0f);
-#endif
-}
 template <bool SYN>  // SYN: dY[m][k] = dq[m] * wq[k] (scalar head), else dY is read from memory
 __device__ __forceinline__ void lnbwd_body(const LnBwdTask& T, int bid, float (*red)[16][16]) {
     const int local = bid - T.tile0;
@@ -1260,12 +1284,14 @@ __device__ __forceinline__ void lnbwd_body(const LnBwdTask& T, int bid, float (*
         const float mean = ldg(T.stats + 2 * row), rstd = ldg(T.stats + 2 * row + 1);
         const float* dy = T.dY + (size_t)row * T.ld;
         const float* z = T.Z + (size_t)row * T.ld;
+        const float* gv = T.Gv + (size_t)row * T.ld;
         const float dqr = SYN ? ldg(T.dq + (size_t)row * T.ldq) : 0.f;
-        float zz[16], dd[16], gm[16];  // H <= 1024: <= 16 elements per lane, k = lane + 64 i; all loads issued first
+        float zz[16], dd[16], gm[16], gq[16];  // H <= 1024: <= 16 elements per lane, k = lane + 64 i; all loads issued first
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int k = min(lane + 64 * i, T.H - 1);
             zz[i] = ldg(z + k);
+            gq[i] = ldg(gv + k);
             dd[i] = SYN ? dqr * ldg(T.wq + (size_t)k * T.ldw) : ldg(dy + k);
             gm[i] = ldg(T.gamma + k);
         }
@@ -1274,9 +1300,8 @@ __device__ __forceinline__ void lnbwd_body(const LnBwdTask& T, int bid, float (*
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int k = lane + 64 * i;
-            float g;
-            gelu_both(zz[i], g, dg[i]);
-            xh[i] = (g - mean) * rstd;
+            dg[i] = zz[i];
+            xh[i] = (gq[i] - mean) * rstd;
             d[i] = dd[i] * gm[i];
             if (k < T.width) { s1 += d[i]; s2 += d[i] * xh[i]; }
         }
@@ -1306,12 +1331,12 @@ __device__ __forceinline__ void lnbwd_body(const LnBwdTask& T, int bid, float (*
                     const int m = min(m0 + 16 * u, T.M - 1);
                     mn[u] = ldg(T.stats + 2 * m); rs[u] = ldg(T.stats + 2 * m + 1);
                     dv[u] = SYN ? ldg(T.dq + (size_t)m * T.ldq) * wc : ldg(T.dY + (size_t)m * T.ld + col);
-                    zv[u] = ldg(T.Z + (size_t)m * T.ld + col);
+                    zv[u] = ldg(T.Gv + (size_t)m * T.ld + col);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (m0 + 16 * u < T.M) {
-                        const float xh = (gelu_f(zv[u]) - mn[u]) * rs[u];
+                        const float xh = (zv[u] - mn[u]) * rs[u];
                         sg += dv[u] * xh; sb += dv[u];
                     }
                 }
@@ -1373,11 +1398,13 @@ struct PrepArgs {
     // visual agents: the "observation" block of each network input is that module's encoding of the batch images
     // (agents/fql.py:196-202; [B, od] each, row b = batch row b; E_os holds [obs ; next_obs] = 2B rows); null otherwise
     const float *E_c, *E_t, *E_bc, *E_os;
+    int tl;   // timeline id (diagnostics)
 };
 
 // agents/fql.py:52-56 (x_t, vel), :144-150 (noise), utils/datasets.py:64-100 (index draw + gather),
 // utils/networks.py:191,229-231 (concatenate) -- one pass builds every network input of the step.
 __global__ __launch_bounds__(FQL_THREADS) void fql_prep_kernel(PrepArgs P) {
+    tl_enter(P.tl);
     const SrcDesc& S = *P.src;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + wave;
@@ -1636,6 +1663,7 @@ struct AdamArgs {
     int chunk0;       // first chunk of this launch (per-module launches of the fused single-GPU update)
     int critic_size;
     float lr, tau;
+    int tl;
 };
 __device__ __forceinline__ int f2ord(float f) {
     const int i = __float_as_int(f);
@@ -1645,6 +1673,7 @@ __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i
 
 __global__ __launch_bounds__(FQL_THREADS) void fql_adam_kernel(AdamArgs A) {
     __shared__ float sh[4];
+    tl_enter(A.tl);
     const int cidx = (int)blockIdx.x + A.chunk0;
     const AdamChunk ch = A.chunks[cidx];  // <= 4096 elements, offset and length multiples of 4
     // optax bias correction with count = adam_count + 1 (the counters advance in the finalize kernel afterwards)
@@ -1689,6 +1718,7 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_adam_kernel(AdamArgs A) {
         float* pp = A.partials + 4 * (size_t)cidx;
         pp[0] = tss; pp[1] = tmx; pp[2] = tmn;
     }
+    tl_exit(A.tl);
 }
 
 struct FinalizeArgs {
@@ -1697,6 +1727,7 @@ struct FinalizeArgs {
     const float* partials;   // [n_chunks][4]
     const int* leaf_range;   // [nleaves + 1] chunk index ranges (chunks of a leaf are contiguous)
     int n_chunks, nleaves, do_grad_stats;
+    int tl;
 };
 // grad/max, grad/min, grad/norm = sum over leaves of ||g_leaf||_2 (utils/flax_utils.py:139-157); target-critic leaves
 // contribute zeros, which bound grad/max >= 0 >= grad/min (F5).  Also advances optax count / TrainState.step / RNG step.
@@ -1704,6 +1735,7 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_finalize_kernel(FinalizeArgs 
     __shared__ float sh[4];
     __shared__ float leafn[256];
     DevState* st = A.st;
+    tl_enter(A.tl);
     if (!A.do_grad_stats) return;
     float mx = -INFINITY, mn = INFINITY;
     for (int cidx = threadIdx.x; cidx < A.n_chunks; cidx += FQL_THREADS) {
@@ -2078,7 +2110,7 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_enc_dz_kernel(const EncDzArgs
     const int r = e / P.n, j = e - r * P.n;
     float g = ldg(P.dxa + (size_t)r * P.ld + j);
     if (P.dxb) g += ldg(P.dxb + (size_t)r * P.ld + j);
-    stg(P.dz + e, g * gelu_grad_f(ldg(P.z + e)));
+    stg(P.dz + e, g * ldg(P.z + e));   // P.z holds GELU'(z) (GF_SAVE_Z)
 }
 
 // Experiment only (FQL_BLOCKER): occupies one CU per workgroup (its dynamic LDS leaves no room for a side-lane
@@ -2137,12 +2169,17 @@ __global__ void fql_dataset_add_kernel(float* obs, float* act, float* rew, float
 #ifndef FQL_SIDE_WAVES
 #define FQL_SIDE_WAVES 3
 #endif
+#ifndef FQL_SIDE_VGPRS
+#define FQL_SIDE_VGPRS 168
+#endif
 template <bool BIG>   // BIG: the launch contains 64 x 64 tile tasks (batches >= 1024)
-__global__ __launch_bounds__(FQL_THREADS, BIG ? 2 : FQL_SIDE_WAVES) void fql_side_kernel(const GemmTask* __restrict__ gt, int ngt, const WgradTask* __restrict__ wt,
-                                                                  int nwt, const LnBwdTask* __restrict__ lt, int nlt, int tile_w, int tile_l,
-                                                                  const MiscTask* __restrict__ mt, int tile_m) {
+__device__ __forceinline__ void side_body(const GemmTask* __restrict__ gt, int ngt, const WgradTask* __restrict__ wt, int nwt, const LnBwdTask* __restrict__ lt,
+                                          int nlt, int tile_w, int tile_l, const MiscTask* __restrict__ mt, int tile_m, int prio) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x;
+    if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 3) __builtin_amdgcn_s_setprio(3);
     if (b < tile_w) {
         gemm_tile_dispatch<BIG>(gt[find_task(gt, ngt, b)], lds);
     } else if (b < tile_l) {
@@ -2164,4 +2201,19 @@ __global__ __launch_bounds__(FQL_THREADS, BIG ? 2 : FQL_SIDE_WAVES) void fql_sid
         }
     }
 }
-
+// two kernels: the register budget of the common one is set so that two of its workgroups and one 512-thread Euler-chain
+// workgroup (2 x 104 registers per SIMD) fit a CU together; the 64 x 64 tile body needs twice that
+__global__ __launch_bounds__(FQL_THREADS, FQL_SIDE_WAVES) void fql_side_kernel(
+    const GemmTask* __restrict__ gt, int ngt, const WgradTask* __restrict__ wt, int nwt, const LnBwdTask* __restrict__ lt, int nlt, int tile_w, int tile_l,
+    const MiscTask* __restrict__ mt, int tile_m, int prio, int tl) {
+    tl_enter(tl);
+    side_body<false>(gt, ngt, wt, nwt, lt, nlt, tile_w, tile_l, mt, tile_m, prio);
+    tl_exit(tl);
+}
+__global__ __launch_bounds__(FQL_THREADS, 2) void fql_side_big_kernel(
+    const GemmTask* __restrict__ gt, int ngt, const WgradTask* __restrict__ wt, int nwt, const LnBwdTask* __restrict__ lt, int nlt, int tile_w, int tile_l,
+    const MiscTask* __restrict__ mt, int tile_m, int prio, int tl) {
+    tl_enter(tl);
+    side_body<true>(gt, ngt, wt, nwt, lt, nlt, tile_w, tile_l, mt, tile_m, prio);
+    tl_exit(tl);
+}
