@@ -8,6 +8,8 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
+if os.environ.get("FQL_TL_TORCH"):
+    import torch  # noqa: F401  (use the HIP runtime bundled with torch, as bench.py does)
 
 import fql_amd  # noqa: E402
 from fql_amd import _cabi  # noqa: E402

@@ -250,6 +250,7 @@ struct fql_engine {
     // Euler-chain kernel (fql_chain.h): fragment-major copies of the BC flow's hidden kernels (layers 1..nh-1), of the 16 rows of
     // W0 that start at the action block and of the head kernel, refreshed behind every Adam step of that module
     bool use_chain = false;
+    int fill_lane_full = 1;          // lane of the critic-loss / BC passes (and of their Adam launches) in the single-GPU programs
     std::vector<float*> wf_bc;       // per layer 1..nh-1: [H/4][H][4]
     float *wf_w0 = nullptr, *wf_w4 = nullptr;
     WfragTask* d_wfrag = nullptr;
@@ -1535,13 +1536,16 @@ struct fql_engine {
             }
           }
         }
-        if (getenv("FQL_DUMP")) {
+        // cross-lane edges (computed below) are printed by the dump too: move the dump after them
+        auto dump_program = [&]() {
             int cnt[FQL_LANES] = {};
             for (const Launch& L : pr.launches) {
                 cnt[L.lane]++;
                 int lv = -1;
                 for (int oi = 0; oi < (int)pr.ops.size(); ++oi) if (launch_of[oi] == (int)(&L - pr.launches.data())) lv = pr.ops[oi].level;
-                fprintf(stderr, "[fql] level %3d lane %d type %2d ntasks %2d grid %5d :", lv, L.lane, (int)L.type, L.ntasks, L.grid);
+                fprintf(stderr, "[fql] #%2d level %3d lane %d type %2d ntasks %2d grid %5d waits[", (int)(&L - pr.launches.data()), lv, L.lane, (int)L.type, L.ntasks, L.grid);
+                for (int w : L.waits) fprintf(stderr, "%d ", w);
+                fprintf(stderr, "] :");
                 for (int oi = 0; oi < (int)pr.ops.size(); ++oi) {
                     if (launch_of[oi] != (int)(&L - pr.launches.data())) continue;
                     const Op& o = pr.ops[oi];
@@ -1555,7 +1559,7 @@ struct fql_engine {
             fprintf(stderr, "[fql] launches per lane:");
             for (int l = 0; l < FQL_LANES; ++l) fprintf(stderr, " %d", cnt[l]);
             fprintf(stderr, "\n");
-        }
+        };
         // cross-lane edges: a launch waits for the latest launch of the other lane it depends on (lane streams
         // are in-order, so that covers the earlier ones); skip waits already implied by an earlier wait.
         int waited_upto[FQL_LANES][FQL_LANES];  // [waiting lane][other lane]: highest launch index already waited for
@@ -1579,6 +1583,7 @@ struct fql_engine {
                     waited_upto[L.lane][ol] = need[ol];
                 }
         }
+        if (getenv("FQL_DUMP")) dump_program();
     }
 
     // s2 != nullptr: two-stream issue (graph capture of a two-lane program); otherwise everything goes to `s0` in
@@ -1586,9 +1591,12 @@ struct fql_engine {
     void run_launches(Program& pr, hipStream_t s0, bool fork = false) {
         const bool par = fork && pr.two_lanes;
         hipStream_t ls[FQL_LANES] = {s0, stream2, stream3, stream4};
+        // FQL_FORK_ALL=1 (experiment): lane 0 on a forked stream too, so the origin stream carries nothing but the fork / join events
+        static const bool fork_all = getenv("FQL_FORK_ALL") != nullptr;
         if (par) {
             if (!pr.ev_fork) HIP_CHECK(hipEventCreateWithFlags(&pr.ev_fork, hipEventDisableTiming));
             HIP_CHECK(hipEventRecord(pr.ev_fork, s0));
+            if (fork_all) { ls[0] = stream3; HIP_CHECK(hipStreamWaitEvent(stream3, pr.ev_fork, 0)); }
             for (int l = 1; l < FQL_LANES; ++l) if (pr.lane_used[l]) HIP_CHECK(hipStreamWaitEvent(ls[l], pr.ev_fork, 0));
         }
         static const int only_lane = getenv("FQL_ONLY_LANE") ? atoi(getenv("FQL_ONLY_LANE")) : -1;  // timing experiments
@@ -1603,6 +1611,8 @@ struct fql_engine {
             pr.lane_used[3] = true;
         }
         for (Launch& L : pr.launches) {
+            static const int max_launch = getenv("FQL_MAX_LAUNCH") ? atoi(getenv("FQL_MAX_LAUNCH")) : -1;   // capture-crash bisection
+            if (max_launch >= 0 && (int)(&L - pr.launches.data()) >= max_launch) continue;
             if (only_lane >= 0 && pr.two_lanes && L.lane != only_lane) continue;
             static const int skip_lane = getenv("FQL_SKIP_LANE") ? atoi(getenv("FQL_SKIP_LANE")) : -1;
             if (skip_lane >= 0 && pr.two_lanes && L.lane == skip_lane && L.type != OP_PREP) continue;
@@ -1725,6 +1735,12 @@ struct fql_engine {
                 HIP_CHECK(hipEventRecord(L.ev, s));
             }
         }
+        if (par && fork_all) {
+            static hipEvent_t ev0 = nullptr;
+            if (!ev0) HIP_CHECK(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
+            HIP_CHECK(hipEventRecord(ev0, stream3));
+            HIP_CHECK(hipStreamWaitEvent(s0, ev0, 0));
+        }
         if (par)
             for (int l = 1; l < FQL_LANES; ++l) {
                 if (!pr.lane_used[l]) continue;
@@ -1755,6 +1771,12 @@ struct fql_engine {
             size_t nn = 0;
             hipGraphGetNodes(pr.graph, nullptr, &nn);
             fprintf(stderr, "[fql] instantiate (%zu nodes)\n", nn);
+        }
+        if (const char* dot = getenv("FQL_DOT")) {   // diagnostics: dump every captured graph (nodes + edges) as graphviz
+            static int ndot = 0;
+            char path[512];
+            snprintf(path, sizeof path, "%s.%d.dot", dot, ndot++);
+            (void)hipGraphDebugDotPrint(pr.graph, path, 0);
         }
         HIP_CHECK(hipGraphInstantiate(&pr.exec, pr.graph, nullptr, nullptr, 0));
         if (trace_c) fprintf(stderr, "[fql] instantiated\n");
@@ -1856,14 +1878,40 @@ struct fql_engine {
             op.type = OP_PREP;
             op.prep = PrepArgs{d_src, st, seed, B, od, ad, inp_c, inp_b, ap, X_os, X_bc, X_eu, X_c1, X_c2, X_ct, vel, w_rew, w_mask, w_act,
                                fused_euler ? X_e0 : nullptr, nullptr, nullptr, nullptr, nullptr};
-            op.writes = {X_os, X_bc, X_eu, X_c1, X_c2, X_ct, vel, w_rew, w_mask, w_act};
-            if (fused_euler) op.writes.push_back(X_e0);
+            op.prep.tl = -1; op.prep.part = 0;
+            // One batch-assembly launch per lane (state agents): the side lane then has no dependency on the critical lane at the
+            // start of the update.  (On this runtime a graph branch whose first node waits for a node of the other branch starts
+            // only ~16 launches of that branch later: profiles/r02_timeline_concurrent.txt.)
+            static const bool split_prep = getenv("FQL_NO_SPLIT_PREP") == nullptr;
             if (visual) {
                 op.prep.E_c = eb_c.E; op.prep.E_t = eb_t.E; op.prep.E_bc = eb_bc.E; op.prep.E_os = eb_os.E;
                 op.reads = {eb_c.E, eb_t.E, eb_bc.E, eb_os.E};
             }
-            push(pr, op);
+            if (split_prep && !visual && !split_build) {
+                Op a = op, b = op;
+                a.prep.part = 1;
+                a.writes = {X_eu};
+                if (fused_euler) a.writes.push_back(X_e0);
+                b.prep.part = 2;
+                b.writes = {X_os, X_bc, X_c1, X_c2, X_ct, vel, w_rew, w_mask, w_act};
+                emit_lane = 0; push(pr, a);
+                emit_lane = 1; push(pr, b);
+                emit_lane = 0;
+            } else {
+                op.writes = {X_os, X_bc, X_eu, X_c1, X_c2, X_ct, vel, w_rew, w_mask, w_act};
+                if (fused_euler) op.writes.push_back(X_e0);
+                push(pr, op);
+            }
         }
+        // Three lanes (state agents, single-GPU programs): lane 1 carries only what the one-step actor's backward waits for - the
+        // Q-gradient path (one-step forward, critic(obs, actor actions) forward and input-gradient chain) - in light launches;
+        // the critic-loss passes, the BC pass, every weight gradient and Adam go to lane 2.  Edges between the two forked
+        // lanes run 1 -> 2 only: torch's bundled HIP runtime recurses forever in hipStreamEndCapture when two forked streams wait
+        // on each other in BOTH directions (hip::Stream::EndCapture walks the cycle; the system ROCm 7.2 runtime does not).
+        static const bool lanes3_env = getenv("FQL_LANES3") ? atoi(getenv("FQL_LANES3")) != 0 : true;
+        const bool lanes3 = lanes3_env && !visual && !split_build;
+        const int fill_lane = lanes3 ? 2 : 1;
+        if (!split_build) fill_lane_full = fill_lane;
         place("os", 1, true);
         // one-step actor on [next_obs|eps1 ; obs|z ; obs|eps2]  (agents/fql.py:25,65,82)
         emit_forward(pr, p_os, with_grads, GF_OS_SCATTER, X_ct, X_c2);
@@ -1875,12 +1923,12 @@ struct fql_engine {
             op.writes = {I_MSE};
             push(pr, op);
         }
-        place("c1", 1, true);
+        place("c1", fill_lane, true);
         // critic(obs, actions) with grad params; target critic(next_obs, next_actions)  (fql.py:28,36)
         for (int e = 0; e < 2; ++e) emit_forward(pr, p_c1[e], with_grads);
-        place("ct", 1, true);
+        place("ct", fill_lane, true);
         for (int e = 0; e < 2; ++e) emit_forward(pr, p_ct[e], false);
-        place("c1", 1, true);
+        place("c1", fill_lane, true);
         {
             Op op{};
             op.type = OP_LOSS_CRITIC;
@@ -1895,7 +1943,8 @@ struct fql_engine {
         // The critic's weight gradients gate nothing but Adam: they are emitted after the Q-gradient chain, whose levels on lane 1
         // then carry fewer tiles and finish earlier - and with them the one-step actor's backward tail (2127 -> 2170 updates/s;
         // deferring the BC flow's too: 2161, the critic's whole backward chain: 2050).  FQL_LATE_WGRAD: 0 off, 1 both, 2 critic, 3 bc.
-        static const int late_wgrad = getenv("FQL_LATE_WGRAD") ? atoi(getenv("FQL_LATE_WGRAD")) : 2;
+        static const int late_wgrad_env = getenv("FQL_LATE_WGRAD") ? atoi(getenv("FQL_LATE_WGRAD")) : -1;
+        const int late_wgrad = late_wgrad_env >= 0 ? late_wgrad_env : (lanes3 ? 0 : 2);   // (three lanes: they are on lane 2, out of the Q-gradient path's launches anyway)
         std::vector<Op> late_ops;
         if ((late_wgrad == 1 || late_wgrad == 2) && with_grads) defer_wgrads = &late_ops;
         if (with_grads)
@@ -1907,7 +1956,7 @@ struct fql_engine {
             emit_encoder_backward(pr, eb_c, 0, B, p_c1[0].dx0, p_c1[1].dx0, nets[NET_C0].in_p());
         }
         // BC flow-matching pass (fql.py:52-59)
-        place("bc", 1, true);
+        place("bc", fill_lane, true);
         emit_forward(pr, p_bc, with_grads);
         {
             Op op{};
@@ -1941,8 +1990,11 @@ struct fql_engine {
             push(pr, op);
         }
         defer_wgrads = nullptr;
-        if (with_grads)
-            for (int e = 0; e < 2; ++e) emit_backward(pr, p_c2[e], 0, B, false, true, I_CR);  // in phase with the c1 chain
+        if (with_grads) {
+            // two lanes: in phase with the c1 chain (shared launches); three lanes: on its own, as early as its inputs exist
+            static const bool c2_align = getenv("FQL_NO_C2_ALIGN") == nullptr;
+            for (int e = 0; e < 2; ++e) emit_backward(pr, p_c2[e], 0, B, false, true, (c2_align && !lanes3) ? I_CR : nullptr);
+        }
         for (Op& w : late_ops) {   // the critic's and the BC flow's weight gradients only after the Q-gradient chain (they gate nothing)
             w.reads.push_back(p_c2[0].dx0); w.reads.push_back(p_c2[1].dx0);
             emit_lane = w.lane;
@@ -1976,7 +2028,7 @@ struct fql_engine {
                 op.writes.push_back(p_os_bwd.dz.back());
             }
             const int keep = emit_lane;
-            if (fuse_la && !split_build) emit_lane = 1;
+            if (fuse_la && !split_build) emit_lane = fill_lane;
             push(pr, op);
             emit_lane = keep;
         }
@@ -2092,8 +2144,8 @@ struct fql_engine {
             emit_lane = lane;
             push(pr, a);
         };
-        adam_for(2, {NET_C0, NET_C1}, 1);
-        adam_for(0, {NET_BC}, 1);
+        adam_for(2, {NET_C0, NET_C1}, fill_lane_full);
+        adam_for(0, {NET_BC}, fill_lane_full);
         emit_wfrag(pr);   // lane 1, behind the BC flow's Adam: the next update's chain reads the copies
         adam_for(1, {NET_OS}, 0);
         Op f{};
@@ -2697,8 +2749,10 @@ static hipStream_t pick(fql_handle h, void* s) { return s ? (hipStream_t)s : h->
 
 static void run_program(fql_handle h, Program& pr, hipStream_t s) {
     static const bool no_graph = getenv("FQL_NO_GRAPH") != nullptr;
+    static const bool eager_lanes = getenv("FQL_NO_GRAPH") && atoi(getenv("FQL_NO_GRAPH")) == 2;   // eager launches on the lane streams
     static const bool split_default = getenv("FQL_SPLIT_DEFAULT") != nullptr;  // experiment: host-launched lane graphs
-    if (no_graph) h->run_launches(pr, s);
+    if (eager_lanes) h->run_launches(pr, s, true);
+    else if (no_graph) h->run_launches(pr, s);
     else if (split_default && (&pr == &h->prog_fwdbwd) && h->split_ok && s != h->stream2) h->launch_split(s, h->stream2);
     else HIP_CHECK(hipGraphLaunch(pr.exec, s));
 }

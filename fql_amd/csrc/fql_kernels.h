@@ -1399,6 +1399,8 @@ struct PrepArgs {
     // (agents/fql.py:196-202; [B, od] each, row b = batch row b; E_os holds [obs ; next_obs] = 2B rows); null otherwise
     const float *E_c, *E_t, *E_bc, *E_os;
     int tl;   // timeline id (diagnostics)
+    int part; // 0: every output; 1: the critical lane's inputs only (X_eu, X_e0); 2: everything else (one launch per lane: neither lane
+              //    then waits for the other at the start of the update)
 };
 
 // agents/fql.py:52-56 (x_t, vel), :144-150 (noise), utils/datasets.py:64-100 (index draw + gather),
@@ -1439,7 +1441,7 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_prep_kernel(PrepArgs P) {
             zz = S.z ? S.z[(size_t)b * ad + a] : rng_normal(P.key, step, 4u, (uint32_t)b, (uint32_t)a);
             e2 = S.eps2 ? S.eps2[(size_t)b * ad + a] : rng_normal(P.key, step, 5u, (uint32_t)b, (uint32_t)a);
         }
-        if (j < P.inp_c) {
+        if (j < P.inp_c && P.part != 1) {
             const size_t w = P.inp_c;
             P.X_os[(size_t)b * w + j] = is_obs ? no_os : e1;         // sample_actions(next_obs)  fql.py:25
             P.X_os[(size_t)(B + b) * w + j] = is_obs ? o_os : zz;    // onestep(obs, noises)      fql.py:65
@@ -1451,16 +1453,18 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_prep_kernel(PrepArgs P) {
         if (j < P.inp_b) {
             const size_t w = P.inp_b;
             const float xt = (1.0f - tt) * xx + tt * av;             // fql.py:55
-            P.X_bc[(size_t)b * w + j] = is_obs ? o_bc : (is_act ? xt : (j == od + ad ? tt : 0.f));
-            P.X_eu[(size_t)b * w + j] = is_obs ? o_bc : (is_act ? zz : 0.f);  // t_0 = 0; encoded once (fql.py:162-163)
-            if (P.X_e0) P.X_e0[(size_t)b * w + j] = is_obs ? o_bc : 0.f;
+            if (P.part != 1) P.X_bc[(size_t)b * w + j] = is_obs ? o_bc : (is_act ? xt : (j == od + ad ? tt : 0.f));
+            if (P.part != 2) {
+                P.X_eu[(size_t)b * w + j] = is_obs ? o_bc : (is_act ? zz : 0.f);  // t_0 = 0; encoded once (fql.py:162-163)
+                if (P.X_e0) P.X_e0[(size_t)b * w + j] = is_obs ? o_bc : 0.f;
+            }
         }
-        if (is_act) {
+        if (is_act && P.part != 1) {
             P.vel[(size_t)b * P.ap + a] = av - xx;                     // fql.py:56
             P.w_act[(size_t)b * P.ap + a] = av;
         }
     }
-    if (lane == 0) {
+    if (lane == 0 && P.part != 1) {
         P.w_rew[b] = S.rew[src];
         P.w_mask[b] = S.mask[src];
     }

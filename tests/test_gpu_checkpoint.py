@@ -57,7 +57,7 @@ def test_persistent_euler_chain_matches_oracle(B):
         _, ig = agent.update(batch, noise=nz)
         _, ir = ref.update(batch, nz)
         assert_info_close(ig, ir, rtol=1e-4, atol=1e-5)
-    assert agent.stats()['launches_per_update'] < 50     # the chain is one launch on this path
+    assert agent.stats()['launches_per_update'] < 60     # the chain is one launch on this path (30 in the default program)
 
 
 def test_jax_key_paths_match_oracle_with_host_threefry_noise():
