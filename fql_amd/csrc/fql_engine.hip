@@ -2236,7 +2236,9 @@ struct fql_engine {
                 // default: on when every team has >= 4 row tiles to walk per phase (B >= 1024: +5 %); at B = 256 / 512 the chain
                 // is shorter but the update is not.  FQL_PEC=1 / 0 forces it on / off.
                 const int pec_tiles = pec_teams >= 1 ? B / 16 / pec_teams : 0;
-                const bool pec_want = getenv("FQL_PEC") ? atoi(getenv("FQL_PEC")) != 0 : pec_tiles >= 4;
+                // opt-in only (FQL_PEC=1): since round 2 the launch-based chain on fql_chain_kernel is faster at every batch size
+                // measured (B = 1024: 989 against 970 updates/s), and a persistent kernel that needs co-residency stays off by default
+                const bool pec_want = getenv("FQL_PEC") ? atoi(getenv("FQL_PEC")) != 0 : false;
                 use_pec = fused_euler && same && pec_want && pec_teams >= 1 && pec_tiles <= PEC_MAX_TILES && cfg.flow_steps <= 20;
                 if (use_pec) {
                     pec_epoch = (unsigned*)dalloc(W, (size_t)pec_teams + 1);
