@@ -2961,6 +2961,37 @@ void* fql_stream(fql_handle h) { return h ? (void*)h->stream : nullptr; }
 
 }  // extern "C"
 
+// Diagnostic only (not in include/fql_amd.h): copy a workspace buffer of the last update to the host, so tests can look at what the
+// production RNG / gather path actually produced.  which: 0 X_os [3B, inp_c], 1 X_bc [B, inp_b], 2 vel [B, ap], 3 w_act [B, ap],
+// 4 X_c1 [B, inp_c], 5 w_rew [B], 6 w_mask [B], 7 in_idx (int64 [B], frames path), 8 in_crop (int32 [B][2], frames path),
+// 9 X_eu [B, inp_b].  *dims receives {rows, row stride in elements}.
+extern "C" int fql_debug_workspace(fql_handle h, int which, void* out, size_t bytes, int* dims) {
+    if (!h || !out) return FQL_E_INVALID;
+    const int B = h->B, ic = h->nets[NET_OS].in_p(), ib = h->nets[NET_BC].in_p(), ap = pad16(h->cfg.act_dim);
+    const void* src = nullptr;
+    size_t n = 0, esz = sizeof(float);
+    int rows = B, ld = 1;
+    switch (which) {
+        case 0: src = h->X_os; rows = 3 * B; ld = ic; break;
+        case 1: src = h->X_bc; ld = ib; break;
+        case 2: src = h->vel; ld = ap; break;
+        case 3: src = h->w_act; ld = ap; break;
+        case 4: src = h->X_c1; ld = ic; break;
+        case 5: src = h->w_rew; break;
+        case 6: src = h->w_mask; break;
+        case 7: src = h->in_idx; esz = sizeof(int64_t); break;
+        case 8: src = h->in_crop; esz = sizeof(int); ld = 2; break;
+        case 9: src = h->X_eu; ld = ib; break;
+        default: return FQL_E_INVALID;
+    }
+    if (!src) return FQL_E_NOTFOUND;
+    n = (size_t)rows * ld * esz;
+    if (dims) { dims[0] = rows; dims[1] = ld; }
+    if (bytes < n) return FQL_E_INVALID;
+    if (hipDeviceSynchronize() != hipSuccess) return FQL_E_HIP;
+    return hipMemcpy(out, src, n, hipMemcpyDeviceToHost) == hipSuccess ? FQL_OK : FQL_E_HIP;
+}
+
 // Diagnostic only (not in include/fql_amd.h), -DFQL_TIMELINE builds: per launch of the single-graph update (prog_full) lane, op type,
 // grid and the device wall-clock times (us, relative to the first entry) of its first / last workgroup entry and last exit.
 // reset = 1 clears the table (call before the update to be examined).  Returns the number of launches, or < 0.
