@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('FQL_AMD_LIB') or os.path.join(_HERE, 'libfql_amd.so')   # (override: kernel-variant builds under experiments/)
 
 FQL_MAX_HIDDEN = 8
+FQL_STREAM_LEGACY = 1   # (void*)1 == hipStreamLegacy: the legacy default stream (torch's default stream)
 FQL_NUM_INFO = 13
 FQL_OK, FQL_E_INVALID, FQL_E_NODEVICE, FQL_E_HIP, FQL_E_STATE, FQL_E_NOTFOUND = 0, -1, -2, -3, -4, -5
 
@@ -60,6 +61,7 @@ SYMBOLS = {
     'fql_grad_buckets': (_I, [_VP, C.POINTER(_SZ), C.POINTER(_SZ)]),
     'fql_grad_buffer': (_I, [_VP, C.POINTER(_VP), C.POINTER(_SZ)]),
     'fql_set_grad_scale': (_I, [_VP, _F]),
+    'fql_set_rng_stream': (_I, [_VP, _U64]),
     'fql_total_loss': (_I, [_VP] + _BATCH + [C.POINTER(FqlNoise), C.POINTER(_F), C.POINTER(_F), _VP]),
     'fql_sample_actions': (_I, [_VP, _VP, _I, _VP, _U64, _VP, _VP]),
     'fql_flow_actions': (_I, [_VP, _VP, _VP, _I, _VP, _VP]),

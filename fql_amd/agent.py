@@ -156,12 +156,15 @@ class FQLAgent:
 
     @staticmethod
     def _stream(args):
-        """Run on torch's current stream when any argument lives on the GPU (keeps torch's caching
-        allocator and the engine stream-ordered); otherwise the engine's own stream (NULL)."""
+        """Run on torch's current stream when any argument lives on the GPU (keeps torch's caching allocator and the engine
+        stream-ordered, including the dtype / contiguity temporaries made just before the call); otherwise the engine's own
+        stream (NULL).  torch's DEFAULT stream has the handle 0, which the C ABI reads as "no stream": it is passed as
+        FQL_STREAM_LEGACY (hipStreamLegacy) instead, so the engine's graph is enqueued on that very stream."""
         for a in args:
             k = getattr(a, 'keep', None)
             if k is not None and hasattr(k, 'is_cuda') and k.is_cuda:
-                return _torch().cuda.current_stream().cuda_stream
+                h = _torch().cuda.current_stream().cuda_stream
+                return h if h else _cabi.FQL_STREAM_LEGACY
         return None
 
     def _batch_args(self, batch):
@@ -386,6 +389,10 @@ class FQLAgent:
 
     def set_grad_scale(self, scale: float):
         self._check(self._lib.fql_set_grad_scale(self._h, float(scale)))
+
+    def set_rng_stream(self, stream_id: int):
+        """Mix `stream_id` (the rank) into the device RNG key: same seed on every replica, different draws."""
+        self._check(self._lib.fql_set_rng_stream(self._h, int(stream_id) & 0xFFFFFFFFFFFFFFFF))
 
     # -- parameters / optimizer state (reference tree layout, utils/flax_utils.py:16-50) ---------
     def leaves(self):

@@ -563,15 +563,16 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_img_index_kernel(const ImgInd
     const int b = blockIdx.x * FQL_THREADS + threadIdx.x;
     if (b >= P.B) return;
     const uint64_t step = P.st->rng_step;
-    int64_t i = P.idx_in ? P.idx_in[b] : P.lo + (int64_t)(((uint64_t)rng_u32(P.key, step, 7u, (uint32_t)b) * (uint64_t)P.span) >> 32);
+    const uint64_t key = P.key ^ (P.st->rng_stream * 0x9E3779B97F4A7C15ull);
+    int64_t i = P.idx_in ? P.idx_in[b] : P.lo + (int64_t)(((uint64_t)rng_u32(key, step, 7u, (uint32_t)b) * (uint64_t)P.span) >> 32);
     P.idx[b] = i;
     P.init[b] = P.ds_init[i];
     int cy = P.pad, cx = P.pad;   // crop_from == padding: the identity slice
     if (P.crop_in) { cy = P.crop_in[2 * b]; cx = P.crop_in[2 * b + 1]; }
-    else if (P.p_aug > 0.f && rng_uniform(P.key, step, 8u, 0u) < P.p_aug) {   // ONE coin per batch (utils/datasets.py:90-92)
+    else if (P.p_aug > 0.f && rng_uniform(key, step, 8u, 0u) < P.p_aug) {   // ONE coin per batch (utils/datasets.py:90-92)
         const uint32_t w = 2u * (uint32_t)P.pad + 1u;
-        cy = (int)(((uint64_t)rng_u32(P.key, step, 9u, (uint32_t)b) * w) >> 32);
-        cx = (int)(((uint64_t)rng_u32(P.key, step, 10u, (uint32_t)b) * w) >> 32);
+        cy = (int)(((uint64_t)rng_u32(key, step, 9u, (uint32_t)b) * w) >> 32);
+        cx = (int)(((uint64_t)rng_u32(key, step, 10u, (uint32_t)b) * w) >> 32);
     }
     P.crop[2 * b] = cy; P.crop[2 * b + 1] = cx;
 }

@@ -1584,6 +1584,18 @@ struct fql_engine {
                 }
         }
         if (getenv("FQL_DUMP")) dump_program();
+        // Two FORKED lanes (>= 1; lane 0 is the capture's origin stream) must not wait on each other in both directions: the HIP
+        // runtime bundled with torch 2.10 (ROCm 7.0) walks the resulting cycle of parallel capture streams forever in
+        // hip::Stream::EndCapture (a segmentation fault by stack exhaustion; diagnosed with rocgdb, profiles/r02_capture_crash.txt).
+        // The default programs keep such edges one-directional by construction; placement overrides that do not are refused.
+        bool edge[FQL_LANES][FQL_LANES] = {};
+        for (const Launch& L : pr.launches)
+            for (int w : L.waits) edge[pr.launches[w].lane][L.lane] = true;
+        for (int a = 1; a < FQL_LANES; ++a)
+            for (int b = a + 1; b < FQL_LANES; ++b)
+                if (edge[a][b] && edge[b][a])
+                    invalid("lane placement makes lanes %d and %d wait on each other in both directions: not capturable on this HIP runtime "
+                            "(hipStreamEndCapture recursion); move one of the passes", a, b);
     }
 
     // s2 != nullptr: two-stream issue (graph capture of a two-lane program); otherwise everything goes to `s0` in
@@ -2241,6 +2253,17 @@ struct fql_engine {
                 const bool pec_want = getenv("FQL_PEC") ? atoi(getenv("FQL_PEC")) != 0 : false;
                 use_pec = fused_euler && same && pec_want && pec_teams >= 1 && pec_tiles <= PEC_MAX_TILES && cfg.flow_steps <= 20;
                 if (use_pec) {
+                    // every workgroup of the persistent chain spins on its team mates: all of them must be resident at once
+                    const size_t lds = ((size_t)16 * (H + 4) + 1024 + 576 + 512 * (size_t)pec_tiles) * sizeof(float);
+                    int per_cu = 0;
+                    const hipError_t oe = H == 512 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fql_euler_persistent_kernel<512>, FQL_THREADS, lds)
+                                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fql_euler_persistent_kernel<256>, FQL_THREADS, lds);
+                    if (oe != hipSuccess || per_cu < 1 || pec_teams * (H / 32) > num_cus) {   // one workgroup per CU: never rely on a second slot
+                        (void)hipGetLastError();
+                        use_pec = false;
+                    }
+                }
+                if (use_pec) {
                     pec_epoch = (unsigned*)dalloc(W, (size_t)pec_teams + 1);
                     for (int i = 0; i < 2; ++i) pec_g[i] = (fql_u64*)dalloc(W, (size_t)B * H * 2);
                     pec_vg = (fql_u64*)dalloc(W, (size_t)(H / 32) * B * 16 * 2);
@@ -2484,7 +2507,7 @@ struct fql_engine {
         evals[n_pad] = std::move(ev);
         return ref;
     }
-    void eval_rows(bool flow, const float* obs, const float* noise, uint64_t sd, int n, float* out, hipStream_t s) {
+    void eval_rows(bool flow, const float* obs, const float* noise, uint64_t sd, int n, float* out, hipStream_t s, bool own_stream = false) {
         if (n <= 0) invalid("n must be positive (got %d)", n);
         if (!obs || !out) invalid("observations/out must not be NULL");
         if (flow && !noise) invalid("noises must not be NULL");
@@ -2517,6 +2540,9 @@ struct fql_engine {
             HIP_CHECK(hipGetLastError());
             if (!dev_out) {
                 HIP_CHECK(hipMemcpyAsync(dst, ev.st_out, (size_t)m * ad * sizeof(float), hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+            } else if (own_stream) {
+                // device output on the engine's private stream: the caller has no handle to order its reads against, so finish here
                 HIP_CHECK(hipStreamSynchronize(s));
             }
         }
@@ -2747,6 +2773,8 @@ int fql_set_step(fql_handle h, int64_t adam_count, int64_t train_step) {
     });
 }
 
+// NULL = the engine's own stream; FQL_STREAM_LEGACY ((void*)1 == hipStreamLegacy) = the legacy default stream, i.e. the stream
+// torch's *default* stream maps to (its handle reads 0, which cannot be told from "no stream" here); anything else is a hipStream_t.
 static hipStream_t pick(fql_handle h, void* s) { return s ? (hipStream_t)s : h->stream; }
 
 static void run_program(fql_handle h, Program& pr, hipStream_t s) {
@@ -2807,6 +2835,14 @@ int fql_set_grad_scale(fql_handle h, float scale) {
     });
 }
 
+int fql_set_rng_stream(fql_handle h, uint64_t stream_id) {
+    if (!h) return FQL_E_INVALID;
+    FQL_TRY(h, {
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(&h->d_state->rng_stream, &stream_id, sizeof stream_id, hipMemcpyHostToDevice));
+    });
+}
+
 int fql_total_loss(fql_handle h, const float* obs, const float* act, const float* rew, const float* mask, const float* nobs,
                    int batch_size, const fql_noise* noise, float* loss, float* info10, void* stream) {
     if (!h) return FQL_E_INVALID;
@@ -2824,11 +2860,11 @@ int fql_total_loss(fql_handle h, const float* obs, const float* act, const float
 
 int fql_sample_actions(fql_handle h, const float* obs, int n, const float* noise, uint64_t seed, float* out, void* stream) {
     if (!h) return FQL_E_INVALID;
-    FQL_TRY(h, h->eval_rows(false, obs, noise, seed, n, out, pick(h, stream)));
+    FQL_TRY(h, h->eval_rows(false, obs, noise, seed, n, out, pick(h, stream), stream == nullptr));
 }
 int fql_flow_actions(fql_handle h, const float* obs, const float* noises, int n, float* out, void* stream) {
     if (!h) return FQL_E_INVALID;
-    FQL_TRY(h, h->eval_rows(true, obs, noises, 0, n, out, pick(h, stream)));
+    FQL_TRY(h, h->eval_rows(true, obs, noises, 0, n, out, pick(h, stream), stream == nullptr));
 }
 
 int fql_dataset_upload(fql_handle h, int64_t n, int64_t capacity, const float* obs, const float* act, const float* rew,

@@ -1366,6 +1366,7 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_lnbwd_kernel(const LnBwdTask*
 // ------------------------------------------------------------------------------------------------
 struct DevState {
     uint64_t rng_step;   // advanced once per update (keys the Philox streams)
+    uint64_t rng_stream; // mixed into the Philox key: 0 by default, the rank in data-parallel runs (fql_set_rng_stream)
     int64_t adam_count;  // optax count
     int64_t train_step;  // TrainState.step
     double b1pow, b2pow; // 0.9^count, 0.999^count
@@ -1412,15 +1413,16 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_prep_kernel(PrepArgs P) {
     const int b = blockIdx.x * 4 + wave;
     if (b >= P.B) return;
     const uint64_t step = P.st->rng_step;
+    const uint64_t key = P.key ^ (P.st->rng_stream * 0x9E3779B97F4A7C15ull);   // same create seed on every rank, different draws
     int64_t src = b;
     if (S.idx) src = S.idx[b];
-    else if (S.use_rng_idx) src = S.lo + (int64_t)(((uint64_t)rng_u32(P.key, step, 7u, (uint32_t)b) * (uint64_t)S.span) >> 32);
+    else if (S.use_rng_idx) src = S.lo + (int64_t)(((uint64_t)rng_u32(key, step, 7u, (uint32_t)b) * (uint64_t)S.span) >> 32);
     const int od = P.od, ad = P.ad, B = P.B;
     const bool vis = P.E_c != nullptr;
     const float* obs = vis ? nullptr : S.obs + (size_t)src * od;
     const float* nobs = vis ? nullptr : S.nobs + (size_t)src * od;
     const float* act = S.act + (size_t)src * ad;
-    const float tt = S.t ? S.t[b] : rng_uniform(P.key, step, 3u, (uint32_t)b);
+    const float tt = S.t ? S.t[b] : rng_uniform(key, step, 3u, (uint32_t)b);
     const int maxw = P.inp_c > P.inp_b ? P.inp_c : P.inp_b;
     for (int j = lane; j < maxw; j += 64) {
         const bool is_obs = j < od, is_act = (j >= od) && (j < od + ad);
@@ -1436,10 +1438,10 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_prep_kernel(PrepArgs P) {
         }
         if (is_act) {
             av = act[a];
-            e1 = S.eps1 ? S.eps1[(size_t)b * ad + a] : rng_normal(P.key, step, 1u, (uint32_t)b, (uint32_t)a);
-            xx = S.x0 ? S.x0[(size_t)b * ad + a] : rng_normal(P.key, step, 2u, (uint32_t)b, (uint32_t)a);
-            zz = S.z ? S.z[(size_t)b * ad + a] : rng_normal(P.key, step, 4u, (uint32_t)b, (uint32_t)a);
-            e2 = S.eps2 ? S.eps2[(size_t)b * ad + a] : rng_normal(P.key, step, 5u, (uint32_t)b, (uint32_t)a);
+            e1 = S.eps1 ? S.eps1[(size_t)b * ad + a] : rng_normal(key, step, 1u, (uint32_t)b, (uint32_t)a);
+            xx = S.x0 ? S.x0[(size_t)b * ad + a] : rng_normal(key, step, 2u, (uint32_t)b, (uint32_t)a);
+            zz = S.z ? S.z[(size_t)b * ad + a] : rng_normal(key, step, 4u, (uint32_t)b, (uint32_t)a);
+            e2 = S.eps2 ? S.eps2[(size_t)b * ad + a] : rng_normal(key, step, 5u, (uint32_t)b, (uint32_t)a);
         }
         if (j < P.inp_c && P.part != 1) {
             const size_t w = P.inp_c;

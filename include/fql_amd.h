@@ -17,9 +17,13 @@
  *     the engine detects which (hipPointerGetAttributes) and stages host memory itself.
  *     Pointers are borrowed for the duration of the call only (device pointers: until the work
  *     enqueued by the call has run on `stream`).
- *   - `stream` is a hipStream_t passed as void* (NULL = the engine's own stream).  Calls on one
- *     handle must be serialised by the caller; the engine never synchronises the host except
- *     where documented (host output pointers, get_* calls).
+ *   - `stream` is a hipStream_t passed as void*.  NULL = the engine's own (non-blocking) stream: nothing
+ *     orders it against work the caller has in flight elsewhere, so device pointers passed with a NULL
+ *     stream must already be complete, and calls that write a DEVICE output on the NULL stream finish it
+ *     before returning.  FQL_STREAM_LEGACY ((void*)1, the value of hipStreamLegacy) = the legacy default
+ *     stream - what torch's *default* stream is (its handle reads 0 and cannot be told from NULL): pass it
+ *     when the batch was produced on that stream.  Calls on one handle must be serialised by the caller;
+ *     the engine never synchronises the host except where documented (host output pointers, get_* calls).
  *   - the engine owns params, Adam state, the target network and all workspaces in HBM.
  *     There is NO CPU fallback: without a HIP device fql_create fails with FQL_E_NODEVICE.
  */
@@ -41,6 +45,8 @@ extern "C" {
 #define FQL_E_HIP (-3)      /* a HIP runtime call failed */
 #define FQL_E_STATE (-4)    /* call order violated (e.g. update_end without update_begin) */
 #define FQL_E_NOTFOUND (-5) /* unknown leaf name */
+
+#define FQL_STREAM_LEGACY ((void*)1) /* == hipStreamLegacy: the legacy default (NULL) stream, e.g. torch's default stream */
 
 #define FQL_MAX_HIDDEN 8
 #define FQL_NUM_INFO 13
@@ -147,6 +153,10 @@ int fql_update_from_dataset_begin_split(fql_handle h, const int64_t* idx, int ba
 int fql_grad_buckets(fql_handle h, size_t offsets[2], size_t lengths[2]);
 int fql_grad_buffer(fql_handle h, void** device_ptr, size_t* num_floats);
 int fql_set_grad_scale(fql_handle h, float scale);
+/* Data-parallel replicas are created with the SAME seed (identical initial parameters); stream_id (the rank) is mixed into the
+ * key of the device RNG so that every rank draws different indices inside its shard and different noise (agents/fql.py:24,49-54,
+ * 62-63 draw per-sample noise: ranks must not repeat each other's).  0 = the single-process stream. */
+int fql_set_rng_stream(fql_handle h, uint64_t stream_id);
 
 /* FQLAgent.total_loss(batch, grad_params=None)  agents/fql.py:94-111 -- the validation probe of
  * main.py:284: pure forward, no state change.  loss = critic_loss + actor_loss; info10 = the first 10
