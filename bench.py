@@ -6,12 +6,23 @@ batch=256, hidden 512x4, flow_steps=10, alpha=10, 1,000,000 device-resident tran
 (generator: SURVEY.md 8d), indices and the five noise tensors drawn by the engine's device RNG.
 One "step" = one full FQLAgent.update (forward, backward, grad stats, Adam, Polyak) on one batch.
 
-N > 1 (launched by torch.distributed.run): one process per GPU, replay sharded by transition index,
-gradient all-reduce over RCCL, identical optimizer step on every rank ("scaling": "weak").
+N > 1 (launched by torch.distributed.run): one process per GPU, replay sharded PHYSICALLY by transition index
+(each rank uploads only its rows), gradient all-reduce over RCCL, identical optimizer step on every rank
+("scaling": "weak").
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  Besides the contract fields:
+  roofline      per-kernel: the kernel family with the largest device time per update, its algorithmic FLOPs per launch
+                (GEMM-shaped tasks, SURVEY.md 8d accounting) over its average launch duration, measured HERE with HIP events on
+                the engine's stream (fql_profile_update: the update's launches issued eagerly, one stream, an event around each -
+                the same serialised view rocprofv3 --kernel-trace gives; profiles/r02_kernel_stats.csv must agree);
+                `traffic` / `mfma_util` come from the committed rocprofv3 --pmc summary (profiles/r02_pmc_summary.json), collected
+                in separate passes as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 for 16-byte-per-lane reads on gfx950)
+  whole_update  the same accounting over the whole update on the fenced wall clock
+  kernels       every kernel family of the update: launches, average us, share of the serialised device time
+  cpu_baseline  the torch-CPU restatement of the reference update (oracle/, kind "port") on this host's cores, bounded sample
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -23,9 +34,14 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (matrix), v_mfma_f32_16x16x4_f32
+OP_NAMES = ['fql_gemm16_kernel', 'fql_side_kernel', 'fql_wgrad_kernel', 'fql_lnbwd_kernel', 'fql_prep_kernel', 'fql_post_onestep_kernel',
+            'fql_euler_finish_kernel', 'fql_euler_persistent_kernel', 'fql_loss_critic_kernel', 'fql_loss_q_kernel', 'fql_loss_bc_kernel',
+            'fql_loss_actor_kernel', 'fql_conv_wprep_kernel', 'fql_conv3x3_kernel', 'fql_conv3x3_u8_kernel', 'fql_maxpool_kernel',
+            'fql_maxpool_bwd_kernel', 'fql_conv_wgrad_kernel', 'fql_conv_wgrad_reduce_kernel', 'fql_enc_dz_kernel', 'fql_chain_kernel',
+            'fql_wfrag_kernel', 'fql_adam_kernel', 'fql_finalize_kernel']
 
 
-def cpu_baseline(cfg, od, ad, B, budget_s=20.0, img=None):
+def cpu_baseline(cfg, od, ad, B, budget_s=18.0, img=None):
     """Times the torch-CPU restatement of the reference update (oracle/, "port") on this host.  img = (H, W, C): visual agent."""
     import torch
     from oracle import fql_oracle as O
@@ -44,17 +60,66 @@ def cpu_baseline(cfg, od, ad, B, budget_s=20.0, img=None):
     else:
         ds = O.make_synthetic_dataset(8192, od, ad, seed=0)
         batches = [(O.sample_batch(ds, rng.integers(0, 8192, size=B)), O.make_noise(B, ad, 10 + i)) for i in range(4)]
-    ref.update(*batches[0])  # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        ref.update(*batches[n % 4])
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt > budget_s or n >= 200:
-            break
-    return {'value': round(n / dt, 3), 'unit': 'grad-steps/s', 'cores': int(cores), 'kind': 'port',
-            'sample': f'{n} updates of the torch-CPU restatement (oracle/fql_oracle_torch.py, fp32, B={B}) in {dt:.1f}s; '
-                      'CPU restatement of the reference path, not JAX'}
+
+    def run(budget, cap):
+        ref.update(*batches[0])  # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            ref.update(*batches[n % 4])
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > budget or n >= cap:
+                return n, dt
+    # thread counts: 1, 16, and every core torch sees; the fastest is the reported baseline (with the matrices of
+    # this path - 256 x 512 x 512 - a 128-thread pool is slower than one thread)
+    scan = {}
+    for th, budget, cap in ((1, 5.0, 40), (min(16, cores), 5.0, 60), (cores, budget_s - 10.0, 200)):
+        if th in scan:
+            continue
+        torch.set_num_threads(th)
+        n, dt = run(budget, cap)
+        scan[th] = (n / dt, n, dt)
+    torch.set_num_threads(cores)
+    best = max(scan, key=lambda t: scan[t][0])
+    rate, n, dt = scan[best]
+    return {'value': round(rate, 3), 'unit': 'grad-steps/s', 'cores': int(best), 'kind': 'port',
+            'sample': f'{n} updates of the torch-CPU restatement (oracle/fql_oracle_torch.py, fp32, B={B}) in {dt:.1f}s on {best} thread(s); '
+                      'CPU restatement of the reference path, not JAX',
+            'threads_scan': {str(t): round(v[0], 3) for t, v in scan.items()}, 'host_cores': int(cores)}
+
+
+def profile_kernels(agent, B, reps):
+    """Per-launch device times (HIP events on the engine's stream) of `reps` updates -> per kernel family statistics."""
+    from fql_amd import _cabi
+    lib = _cabi.load()
+    f = lib.fql_profile_update
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6
+    cap = 1024
+    typ, lane, grid = (C.c_int * cap)(), (C.c_int * cap)(), (C.c_int * cap)()
+    us, macs, null_us = (C.c_float * cap)(), (C.c_double * cap)(), C.c_float()
+    fam, nulls = {}, []
+    for r in range(reps + 2):
+        n = f(agent._h, B, cap, typ, lane, grid, us, macs, C.byref(null_us))
+        if n <= 0:
+            return None
+        if r < 2:
+            continue   # warm-up passes
+        nulls.append(null_us.value)
+        # event-to-event interval = launch gap + kernel; the gap is calibrated on an empty kernel (which itself shows ~1.4 us in a trace)
+        gap = max(0.0, null_us.value - 1.4)
+        for i in range(n):
+            d = fam.setdefault(OP_NAMES[typ[i]], {'launches': 0, 'us': 0.0, 'macs': 0.0, 'min_us': 1e9, 'max_us': 0.0, 'raw': 0.0})
+            t = max(0.5, us[i] - gap)
+            d['launches'] += 1; d['us'] += t; d['macs'] += macs[i]; d['raw'] += us[i]
+            d['min_us'] = min(d['min_us'], t); d['max_us'] = max(d['max_us'], t)
+    tot = sum(d['us'] for d in fam.values())
+    out = {}
+    for k, d in fam.items():
+        out[k] = {'launches_per_update': d['launches'] / reps, 'avg_us': d['us'] / d['launches'], 'us_per_update': d['us'] / reps,
+                  'share': d['us'] / tot, 'flop_per_launch': 2.0 * d['macs'] / d['launches'], 'min_us': d['min_us'], 'max_us': d['max_us'],
+                  'event_interval_us': d['raw'] / d['launches'], 'null_interval_us': float(np.median(nulls))}
+    return out
 
 
 def main():
@@ -65,6 +130,7 @@ def main():
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--rows', type=int, default=1_000_000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the per-kernel event pass and the host-batch rate (profiling runs)')
     ap.add_argument('--workload', choices=['state', 'visual'], default='state',
                     help="state = BASELINE.json configs[1] (the headline metric); visual = configs[4] (impala_small, 64x64x9 uint8)")
     ap.add_argument('--frames', type=int, default=20_000, help='frames in the synthetic visual dataset')
@@ -75,8 +141,8 @@ def main():
 
     import torch
     import fql_amd
-    from fql_amd.parallel import DataParallelFQL, shard_range
-    from oracle import fql_oracle as O  # synthetic data generator only
+    from fql_amd.parallel import DataParallelFQL
+    from fql_amd.synthetic import make_synthetic_dataset, make_synthetic_frames
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -94,34 +160,32 @@ def main():
     od, ad, B = args.obs_dim, args.act_dim, args.batch
     cfg = fql_amd.get_config()
     visual = args.workload == 'visual'
+    seed = 0    # the same seed on every rank: DataParallelFQL mixes the rank into the device RNG stream
     if visual:
         # BASELINE.json configs[4] / SURVEY.md 8d "Config 5": uint8 frames, frame_stack 3 -> [64, 64, 9], impala_small encoders,
         # alpha 300, p_aug 0.5; act_dim is a runtime parameter (cube-single: 5)
         ad = 5
-        n = args.rows = args.frames
-        rng = np.random.default_rng(0)
-        term = (rng.random(n) < 1.0 / 200).astype(np.float32); term[-1] = 1
-        ds = {'observations': rng.integers(0, 256, size=(n, 64, 64, 3), dtype=np.uint8),
-              'next_observations': rng.integers(0, 256, size=(n, 64, 64, 3), dtype=np.uint8),
-              'actions': np.clip(rng.uniform(-1, 1, size=(n, ad)), -1 + 1e-5, 1 - 1e-5).astype(np.float32),
-              'rewards': -(rng.random(n) < 0.99).astype(np.float32), 'masks': 1 - term, 'terminals': term}
-        cfg.update(alpha=300.0, batch_size=B, encoder='impala_small')
-        agent = fql_amd.FQLAgent.create(rank, np.zeros((1, 64, 64, 9), np.uint8), ds['actions'][:1], cfg)
-        agent.upload_dataset(ds, frame_stack=3, p_aug=0.5)
+        args.rows = args.frames
+        ds = make_synthetic_frames(args.frames, ad, seed=0)
+        cfg.update(alpha=300.0 if args.alpha is None else args.alpha, batch_size=B, encoder='impala_small')
+        agent = fql_amd.FQLAgent.create(seed, np.zeros((1, 64, 64, 9), np.uint8), ds['actions'][:1], cfg)
+        up_kw = dict(frame_stack=3, p_aug=0.5)
     else:
         cfg.update(alpha=10.0 if args.alpha is None else args.alpha, batch_size=B)
-        ds = O.make_synthetic_dataset(args.rows, od, ad, seed=0)
-        agent = fql_amd.FQLAgent.create(rank, ds['observations'][:1], ds['actions'][:1], cfg)
-        agent.upload_dataset(ds)
-    stream = None if os.environ.get('FQL_BENCH_OWN_STREAM') else torch.cuda.current_stream().cuda_stream
+        ds = make_synthetic_dataset(args.rows, od, ad, seed=0)
+        agent = fql_amd.FQLAgent.create(seed, ds['observations'][:1], ds['actions'][:1], cfg)
+        up_kw = {}
     dp = DataParallelFQL(agent) if dist is not None else None
-    lo, hi = shard_range(args.rows, rank, world)
+    if dp is not None:
+        dp.upload_shard(ds, **up_kw)          # this rank's rows only
+    else:
+        agent.upload_dataset(ds, **up_kw)
 
     def step():
         if dp is not None:
-            dp.update_from_dataset(args.rows, batch_size=B)
+            dp.update_from_dataset(batch_size=B)
         else:
-            agent.update_from_dataset(B, stream=stream)
+            agent.update_from_dataset(B)      # the engine's own stream; no host synchronisation inside the window
 
     def fence():
         if dist is not None:
@@ -131,56 +195,94 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()
     for _ in range(args.steps):
         step()
-    ev1.record()
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the graphs are launched on
     info = agent.read_info()
     st = agent.stats()
 
     if rank == 0:
         steps_per_s = args.steps / dt
         flop_per_step = 2.0 * st['macs_per_update']            # algorithmic: SURVEY.md 8d (12.376 GFLOP at B=256)
-        step_us_dev = dev_ms * 1e3 / args.steps                # device time per update (HIP events on the launch stream)
-        step_us_wall = dt * 1e6 / args.steps                   # fenced wall clock per update (>= device time: enqueue is async)
-        # the events bracket the launch stream only; when the graph's side lanes outlast it the wall clock is the honest
-        # duration, so the roofline is priced on the LARGER of the two
-        achieved = flop_per_step / (max(step_us_dev, step_us_wall) * 1e-6) / 1e12
+        step_us_wall = dt * 1e6 / args.steps                   # fenced wall clock per update
+        whole = flop_per_step / (step_us_wall * 1e-6) / 1e12
+        work = ('visual-cube-shaped synthetic replay (uint8 64x64x9 = 3 stacked frames, act=5), impala_small encoders, '
+                f'batch={B}/GPU, hidden=512x4, flow_steps=10, alpha={cfg["alpha"]:g}, p_aug=0.5, {args.frames} device-resident frames '
+                '(BASELINE.json configs[4])') if visual else (
+            f'antmaze-large-shaped synthetic replay (obs={od}, act={ad}), batch={B}/GPU, hidden=512x4, '
+            f'flow_steps=10, alpha={cfg["alpha"]:g}, 1M device-resident transitions (BASELINE.json configs[1])'
+            if (od, ad, B) == (29, 8, 256) else
+            f'synthetic replay (obs={od}, act={ad}), batch={B}/GPU, hidden=512x4, flow_steps=10, '
+            f'alpha={cfg["alpha"]:g}, device-resident transitions (BASELINE.json configs[2] shape when 40/4/1024)')
         out = {
             'metric': 'FQL gradient-steps/s (batch=256)', 'value': round(steps_per_s * world, 2), 'unit': 'grad-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt * 1e3 / args.steps, 5),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': ('visual-cube-shaped synthetic replay (uint8 64x64x9 = 3 stacked frames, act=5), impala_small encoders, '
-                                    f'batch={B}/GPU, hidden=512x4, flow_steps=10, alpha=300, p_aug=0.5, {args.frames} device-resident frames '
-                                    '(BASELINE.json configs[4])') if visual else
-                                   (f'antmaze-large-shaped synthetic replay (obs={od}, act={ad}), batch={B}/GPU, hidden=512x4, '
-                                    f'flow_steps=10, alpha={cfg["alpha"]:g}, 1M device-resident transitions (BASELINE.json configs[1])'
-                                    if (od, ad, B) == (29, 8, 256) else
-                                    f'synthetic replay (obs={od}, act={ad}), batch={B}/GPU, hidden=512x4, flow_steps=10, '
-                                    f'alpha={cfg["alpha"]:g}, device-resident transitions (BASELINE.json configs[2] shape when 40/4/1024)'),
-                       'parallelism': f'dp{world}', 'samples_per_s': round(steps_per_s * world * B, 1)},
-            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), 'traffic': None,
-                         'kernel': ('whole update graph (fql_conv3x3_kernel + fql_conv_wgrad_kernel dominate)' if visual else
-                                    'whole update graph (MFMA tile kernels fql_gemm16_kernel + fql_wgrad_kernel dominate)'),
-                         'flop_per_launch': flop_per_step, 'launch_us': round(step_us_dev, 3), 'wall_us': round(step_us_wall, 3),
-                         'kernel_launches_per_update': st['launches_per_update']},
+            'config': {'workload': work, 'parallelism': f'dp{world}', 'samples_per_s': round(steps_per_s * world * B, 1)},
+            'whole_update': {'flop': flop_per_step, 'wall_us': round(step_us_wall, 3), 'achieved_tflops': round(whole, 3),
+                             'frac_of_fp32_matrix_peak': round(whole / FP32_MATRIX_PEAK_TFLOPS, 4),
+                             'kernel_launches_per_update': st['launches_per_update']},
             'last_info': {k: round(v, 5) for k, v in info.items()},
         }
+        roof = {'bound': 'mfma', 'achieved': round(whole, 3), 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(whole / FP32_MATRIX_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': 'whole update (per-kernel pass skipped)'}
+        if world == 1 and not args.no_extras:
+            fams = profile_kernels(agent, B, reps=20)
+            if fams:
+                mm = {k: v for k, v in fams.items() if v['flop_per_launch'] > 0}
+                dom = max(mm, key=lambda k: mm[k]['us_per_update'])
+                d = mm[dom]
+                ach = d['flop_per_launch'] / (d['avg_us'] * 1e-6) / 1e12
+                roof = {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': dom,
+                        'flop_per_launch': round(d['flop_per_launch']), 'avg_launch_us': round(d['avg_us'], 3),
+                        'launches_per_update': round(d['launches_per_update'], 2),
+                        'event_interval_us': round(d['event_interval_us'], 3), 'null_interval_us': round(d['null_interval_us'], 3),
+                        'measured': 'HIP events on the engine stream around every launch of 20 updates issued eagerly in program order '
+                                    '(fql_profile_update; serialised like rocprofv3 --kernel-trace); avg_launch_us = event interval minus the '
+                                    'launch gap calibrated on an empty kernel (null interval - 1.4 us)'}
+                pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_summary.json')
+                if os.path.exists(pmc) and not visual:
+                    try:
+                        pj = json.load(open(pmc))
+                        k = pj.get('kernels', {}).get(dom)
+                        if k:
+                            roof['traffic'] = k.get('hbm_bytes_per_launch')
+                            roof['mfma_util'] = k.get('mfma_util')
+                            roof['traffic_source'] = pj.get('source')
+                    except Exception:
+                        pass
+                out['kernels'] = {k: {'launches': round(v['launches_per_update'], 2), 'avg_us': round(v['avg_us'], 2),
+                                      'share': round(v['share'], 4),
+                                      'tflops': round(v['flop_per_launch'] / (v['avg_us'] * 1e-6) / 1e12, 2) if v['flop_per_launch'] else None}
+                                  for k, v in sorted(fams.items(), key=lambda kv: -kv[1]['us_per_update'])}
+            if not visual:
+                # the drop-in loop of main.py:201,216 with HOST batches (numpy -> staged by the engine, lazy infos): PCIe-inclusive rate
+                idx = np.random.default_rng(1).integers(0, args.rows, size=(64, B))
+                hb = [{k: v[i] for k, v in ds.items() if k != 'terminals'} for i in idx]
+                for i in range(50):
+                    agent.update(hb[i % 64])
+                torch.cuda.synchronize(); agent.read_info()
+                t1 = time.perf_counter()
+                nh = 600
+                for i in range(nh):
+                    _, lazy = agent.update(hb[i % 64])
+                agent.read_info()
+                out['host_batch_update'] = {'value': round(nh / (time.perf_counter() - t1), 1), 'unit': 'grad-steps/s',
+                                            'note': 'agent.update(numpy batch) with lazy info, ~70 KB staged H2D per call (PCIe-inclusive; never `value`)'}
+        out['roofline'] = roof
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, od, ad, B, img=(64, 64, 9) if visual else None)
             if not visual:
                 # "loss delta vs the reference" (BASELINE.json metric), against the CPU restatement: one total_loss on the
                 # engine's CURRENT parameters and a fixed synthetic batch with explicit noise, fp64 oracle (checker only)
+                from oracle import fql_oracle as O
                 pb = O.sample_batch(ds, np.random.default_rng(3).integers(0, args.rows, size=B))
                 pn = O.make_noise(B, ad, 4)
                 ref = O.OracleFQL(agent.get_params(), {k: v for k, v in dict(cfg).items() if k != 'rng'}, od, ad, np.float64)

@@ -62,6 +62,8 @@ SYMBOLS = {
     'fql_grad_buffer': (_I, [_VP, C.POINTER(_VP), C.POINTER(_SZ)]),
     'fql_set_grad_scale': (_I, [_VP, _F]),
     'fql_set_rng_stream': (_I, [_VP, _U64]),
+    'fql_info_enqueue': (_I, [_VP, _VP, C.POINTER(_U64)]),
+    'fql_info_wait': (_I, [_VP, _U64, _VP]),
     'fql_total_loss': (_I, [_VP] + _BATCH + [C.POINTER(FqlNoise), C.POINTER(_F), C.POINTER(_F), _VP]),
     'fql_sample_actions': (_I, [_VP, _VP, _I, _VP, _U64, _VP, _VP]),
     'fql_flow_actions': (_I, [_VP, _VP, _VP, _I, _VP, _VP]),

@@ -77,6 +77,43 @@ class _Arg:
             self.ptr = a.ctypes.data
 
 
+class LazyInfo(dict):
+    """The info dict of one update, read from the device only when first looked at (the reference's `update` returns device
+    scalars that main.py:276 reads at log time, so its training loop never synchronises per step).  Behaves as a dict of 13 floats;
+    the first access blocks until that update has run.  Holding it across more than 64 later lazy updates without reading it
+    raises (the engine keeps 64 snapshots)."""
+
+    def __init__(self, agent, ticket):
+        super().__init__()
+        self._agent, self._ticket, self._done = agent, ticket, False
+
+    def _fill(self):
+        if not self._done:
+            buf = (C.c_float * _cabi.FQL_NUM_INFO)()
+            self._agent._check(self._agent._lib.fql_info_wait(self._agent._h, self._ticket, buf))
+            super().update({k: float(buf[i]) for i, k in enumerate(INFO_KEYS)})
+            self._done, self._agent = True, None
+
+    def __getitem__(self, k): self._fill(); return super().__getitem__(k)
+    def __iter__(self): self._fill(); return super().__iter__()
+    def __len__(self): self._fill(); return super().__len__()
+    def __contains__(self, k): self._fill(); return super().__contains__(k)
+    def __repr__(self): self._fill(); return super().__repr__()
+    def __eq__(self, o):
+        self._fill()
+        if isinstance(o, LazyInfo):
+            o._fill()
+        return super().__eq__(o)
+
+    def __ne__(self, o): return not self.__eq__(o)
+    __hash__ = None
+    def get(self, k, d=None): self._fill(); return super().get(k, d)
+    def keys(self): self._fill(); return super().keys()
+    def values(self): self._fill(); return super().values()
+    def items(self): self._fill(); return super().items()
+    def copy(self): self._fill(); return dict(self)
+
+
 class FQLAgent:
     """Flow Q-learning agent backed by the MI355X step engine."""
 
@@ -192,9 +229,11 @@ class FQLAgent:
             self.config['batch_size'] = B
 
     # -- reference API ----------------------------------------------------------------------
-    def update(self, batch, noise: Optional[Dict[str, Any]] = None, want_info: bool = True):
+    def update(self, batch, noise: Optional[Dict[str, Any]] = None, want_info=True):
         """agents/fql.py:122-133.  Returns (agent, info).  `noise` (optional) supplies the five random
-        tensors explicitly (parity runs); by default they come from the engine's device RNG."""
+        tensors explicitly (parity runs); by default they come from the engine's device RNG.
+        `info` is a LazyInfo: a dict of the 13 scalars that is read from the device on first access, so a loop that only logs
+        every N steps (main.py:216,276) never synchronises in between.  want_info=False returns None (no snapshot at all)."""
         B, args = self._batch_args(batch)
         self._ensure_batch(B)
         if noise is None and self.config.get('rng') == 'jax':
@@ -203,7 +242,12 @@ class FQLAgent:
         stream = self._stream(args + nargs)
         self._check(self._lib.fql_update(self._h, *[a.ptr for a in args], B, C.byref(nz) if nz else None, None, stream))
         self._keep = (args, nargs)
-        return self, (self.read_info() if want_info else None)
+        return self, (self._lazy_info(stream) if want_info else None)
+
+    def _lazy_info(self, stream):
+        t = C.c_uint64()
+        self._check(self._lib.fql_info_enqueue(self._h, stream, C.byref(t)))
+        return LazyInfo(self, int(t.value))
 
     def read_info(self) -> Dict[str, float]:
         """The 13 info scalars of the last update (blocks until that update has run)."""
@@ -328,7 +372,7 @@ class FQLAgent:
             self._check(self._lib.fql_update_from_dataset(self._h, ip, B, int(shard[0]), int(shard[1]),
                                                           C.byref(nz) if nz else None, None, stream))
         self._keep = (keep, nargs)
-        return self, (self.read_info() if want_info else None)
+        return self, (self._lazy_info(stream) if want_info else None)
 
     # -- data-parallel halves (fql_amd/parallel.py drives these) ---------------------------------
     def update_begin(self, batch=None, noise=None, idxs=None, shard=(0, 0), batch_size=None, stream=None):

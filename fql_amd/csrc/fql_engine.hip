@@ -156,6 +156,7 @@ struct Launch {
     Op op;                  // arg-struct kernels
     int lane = 0;
     bool tmt2 = false, kbig = false, euler = false;
+    double macs = 0.0;           // algorithmic multiply-accumulates of the GEMM-shaped tasks of this launch (roofline accounting)
     bool side = false;           // merged gemm64 + wgrad + lnbwd launch
     void *table_w = nullptr, *table_l = nullptr, *table_m = nullptr;
     int n_w = 0, n_l = 0, tile_w = 0, tile_l = 0, tile_m = 0;
@@ -303,6 +304,12 @@ struct fql_engine {
     std::map<int, std::unique_ptr<Eval>> evals;
 
     int64_t launches_per_update = 0;
+    // lazily read infos (the reference returns device scalars that are only read at log time, main.py:276): a ring of pinned host
+    // slots, one asynchronous 52-byte copy + event per ticket
+    static constexpr int kInfoRing = 64;
+    float (*h_info_ring)[16] = nullptr;
+    hipEvent_t info_ev[kInfoRing] = {};
+    uint64_t info_seq = 0;
 
     // ---------------------------------------------------------------------------------------
     float* dalloc(std::vector<void*>& owner, size_t nfloats) {
@@ -1560,6 +1567,19 @@ struct fql_engine {
             for (int l = 0; l < FQL_LANES; ++l) fprintf(stderr, " %d", cnt[l]);
             fprintf(stderr, "\n");
         };
+        for (int oi = 0; oi < (int)pr.ops.size(); ++oi) {   // algorithmic MACs per launch (real, unpadded layer widths are within 1 % of these)
+            const Op& o = pr.ops[oi];
+            const int li = launch_of[oi];
+            if (li < 0) continue;
+            double m = 0.0;
+            if (o.type == OP_GEMM || o.type == OP_GEMM64) m = (double)o.gemm.M * o.gemm.N * o.gemm.K;
+            else if (o.type == OP_WGRAD) m = (double)o.wgrad.M * o.wgrad.Kin * o.wgrad.N;
+            else if (o.type == OP_CHAIN) {
+                const double H = cfg.actor_hidden[0];
+                m = (double)o.chain.M * H * H + (o.chain.variant == 0 ? (double)o.chain.M * 16.0 * H : 0.0) + (o.chain.variant == 2 ? (double)o.chain.M * H * o.chain.ap : 0.0);
+            }
+            pr.launches[li].macs += m;
+        }
         // cross-lane edges: a launch waits for the latest launch of the other lane it depends on (lane streams
         // are in-order, so that covers the earlier ones); skip waits already implied by an earlier wait.
         int waited_upto[FQL_LANES][FQL_LANES];  // [waiting lane][other lane]: highest launch index already waited for
@@ -2659,6 +2679,8 @@ int fql_create(const fql_config* cfg, uint64_t seed, fql_handle* out) {
         HIP_CHECK(hipMalloc((void**)&h->d_state, sizeof(DevState)));
         HIP_CHECK(hipMalloc((void**)&h->d_src, sizeof(SrcDesc)));
         HIP_CHECK(hipHostMalloc((void**)&h->h_src_ring, 64 * sizeof(SrcDesc), hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc((void**)&h->h_info_ring, fql_engine::kInfoRing * 16 * sizeof(float), hipHostMallocDefault));
+        for (auto& e : h->info_ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         DevState st{};
         st.rng_step = 0; st.adam_count = 0; st.train_step = 1; st.b1pow = 1.0; st.b2pow = 1.0; st.grad_scale = 1.0f; st.lam = 1.0f;
         const float ninf = -INFINITY, pinf = INFINITY;
@@ -2685,6 +2707,8 @@ int fql_destroy(fql_handle h) {
     }
     hipFree(h->P); hipFree(h->G); hipFree(h->Mu); hipFree(h->Nu); hipFree(h->d_chunks); hipFree(h->d_partials); hipFree(h->d_leaf_range); hipFree(h->d_state); hipFree(h->d_src);
     if (h->h_src_ring) hipHostFree(h->h_src_ring);
+    if (h->h_info_ring) hipHostFree(h->h_info_ring);
+    for (auto& e : h->info_ev) if (e) hipEventDestroy(e);
     hipFree(h->ds_obs); hipFree(h->ds_act); hipFree(h->ds_rew); hipFree(h->ds_mask); hipFree(h->ds_nobs); hipFree(h->ds_row);
     hipFree(h->ds_frames); hipFree(h->ds_next_frames); hipFree(h->ds_init);
     for (void* q : h->enc_allocs) hipFree(q);
@@ -2969,6 +2993,28 @@ int fql_update_from_dataset(fql_handle h, const int64_t* idx, int batch_size, in
     return fql_update_end(h, info13, stream);
 }
 
+int fql_info_enqueue(fql_handle h, void* stream, uint64_t* ticket) {
+    if (!h || !ticket) return FQL_E_INVALID;
+    FQL_TRY(h, {
+        hipStream_t s = pick(h, stream);
+        const uint64_t k = h->info_seq++;
+        const int slot = (int)(k % fql_engine::kInfoRing);
+        HIP_CHECK(hipMemcpyAsync(h->h_info_ring[slot], &h->d_state->info[0], FQL_NUM_INFO * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipEventRecord(h->info_ev[slot], s));
+        *ticket = k;
+    });
+}
+int fql_info_wait(fql_handle h, uint64_t ticket, float* info13_host) {
+    if (!h || !info13_host) return FQL_E_INVALID;
+    if (ticket >= h->info_seq) { h->err = "unknown info ticket"; return FQL_E_INVALID; }
+    if (h->info_seq - ticket > (uint64_t)fql_engine::kInfoRing) { h->err = "info ticket expired (more than 64 later tickets were taken before it was read)"; return FQL_E_STATE; }
+    FQL_TRY(h, {
+        const int slot = (int)(ticket % fql_engine::kInfoRing);
+        HIP_CHECK(hipEventSynchronize(h->info_ev[slot]));
+        std::memcpy(info13_host, h->h_info_ring[slot], FQL_NUM_INFO * sizeof(float));
+    });
+}
+
 int fql_read_info(fql_handle h, float* info13_host) {
     if (!h || !info13_host) return FQL_E_INVALID;
     FQL_TRY(h, {
@@ -2996,6 +3042,62 @@ int fql_stats(fql_handle h, int64_t* launches_per_update, int64_t* macs_per_upda
 void* fql_stream(fql_handle h) { return h ? (void*)h->stream : nullptr; }
 
 }  // extern "C"
+
+// Per-launch device times of ONE update, measured with HIP events on the engine's stream (used by bench.py for the per-kernel
+// roofline: rocprofv3 serialises the graph's lanes, and so does this pass - the launches run eagerly, in program order, on one
+// stream, an event before and after each).  It IS a real update (state advances).  Needs a device-resident dataset.
+// Out, per launch (up to cap): op type (OpType), lane, workgroups, microseconds, algorithmic MACs of its GEMM-shaped tasks.
+// An event-to-event interval holds the launch gap in front of the kernel besides the kernel: *null_us receives the same interval for a
+// one-workgroup kernel that returns at once (median of 32), which the caller subtracts (minus the ~1.4 us such a kernel itself shows
+// in a rocprofv3 trace) to compare with rocprofv3's per-kernel durations.
+extern "C" int fql_profile_update(fql_handle h, int batch_size, int cap, int* type, int* lane, int* grid, float* us, double* macs, float* null_us) {
+    if (!h || !type || !us) return FQL_E_INVALID;
+    if (!h->prog_full.exec) { h->err = "no single-graph update program"; return FQL_E_STATE; }
+    try {
+        hipStream_t s = h->stream;
+        if (null_us) {
+            hipEvent_t a[33];
+            for (auto& e : a) HIP_CHECK(hipEventCreate(&e));
+            HIP_CHECK(hipEventRecord(a[0], s));
+            for (int i = 0; i < 32; ++i) {
+                hipLaunchKernelGGL(fql_extract_kernel, dim3(1), dim3(64), 0, s, (const float*)nullptr, (float*)nullptr, 0, 1, 1);
+                HIP_CHECK(hipEventRecord(a[i + 1], s));
+            }
+            HIP_CHECK(hipStreamSynchronize(s));
+            std::vector<float> v(32);
+            for (int i = 0; i < 32; ++i) { HIP_CHECK(hipEventElapsedTime(&v[i], a[i], a[i + 1])); v[i] *= 1e3f; }
+            std::sort(v.begin(), v.end());
+            *null_us = v[16];
+            for (auto& e : a) hipEventDestroy(e);
+        }
+        h->source_from_dataset(nullptr, batch_size, 0, 0, nullptr, s);
+        Program& pr = h->prog_full;
+        const int n = (int)pr.launches.size();
+        std::vector<hipEvent_t> ev(n + 1);
+        for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
+        Program one;   // one launch at a time through the ordinary launch switch
+        HIP_CHECK(hipEventRecord(ev[0], s));
+        for (int i = 0; i < n; ++i) {
+            one.launches.clear();
+            Launch L = pr.launches[i];
+            L.waits.clear(); L.record_after = false; L.ev = nullptr;
+            one.launches.push_back(L);
+            h->run_launches(one, s, false);
+            HIP_CHECK(hipEventRecord(ev[i + 1], s));
+        }
+        HIP_CHECK(hipStreamSynchronize(s));
+        for (int i = 0; i < n && i < cap; ++i) {
+            const Launch& L = pr.launches[i];
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            type[i] = (int)L.type; if (lane) lane[i] = L.lane; if (grid) grid[i] = L.grid; us[i] = ms * 1e3f;
+            if (macs) macs[i] = L.macs;
+        }
+        for (auto& e : ev) hipEventDestroy(e);
+        return std::min(n, cap);
+    } catch (const Invalid& e) { h->err = e.msg; return FQL_E_INVALID; }
+    catch (const HipError& e) { h->err = e.msg; return FQL_E_HIP; }
+}
 
 // Diagnostic only (not in include/fql_amd.h): copy a workspace buffer of the last update to the host, so tests can look at what the
 // production RNG / gather path actually produced.  which: 0 X_os [3B, inp_c], 1 X_bc [B, inp_b], 2 vel [B, ap], 3 w_act [B, ap],

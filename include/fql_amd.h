@@ -207,6 +207,12 @@ int fql_update_from_frames(fql_handle h, const int64_t* idx, const int32_t* crop
 
 /* Blocking read of the info of the last update (the reference reads lazily at log time, main.py:276). */
 int fql_read_info(fql_handle h, float* info13_host);
+/* Lazy infos, as the reference's `agent, info = agent.update(batch)` returns them (device scalars nobody waits for until they are
+ * logged, main.py:216,276): fql_info_enqueue, called right after an update on the same stream, snapshots that update's 13 scalars
+ * asynchronously (no host synchronisation) and returns a ticket; fql_info_wait blocks until the snapshot has landed and copies it
+ * out.  A ticket expires (FQL_E_STATE) once 64 later tickets have been taken. */
+int fql_info_enqueue(fql_handle h, void* stream, uint64_t* ticket);
+int fql_info_wait(fql_handle h, uint64_t ticket, float* info13_host);
 
 /* Introspection for tests / bench: per-update kernel-launch count, algorithmic MAC count per update
  * (SURVEY.md section 8d figure), and the engine's HIP stream. */

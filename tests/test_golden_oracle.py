@@ -8,7 +8,7 @@ import pytest
 
 from oracle import fql_oracle as O
 
-GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), 'golden', '*.npz')) if 'visual' not in os.path.basename(p))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), 'golden', '*.npz')) if 'visual' not in os.path.basename(p) and not os.path.basename(p).startswith('traj_'))
 VISUAL_GOLDEN = os.path.join(os.path.dirname(__file__), 'golden', 'visual_small.npz')
 
 

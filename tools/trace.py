@@ -8,8 +8,8 @@ path = sys.argv[1]
 files = glob.glob(path + '/**/*kernel_trace.csv', recursive=True)
 rows = [r for r in csv.DictReader(open(files[0])) if 'fql_' in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'prep' in r['Kernel_Name']]
-s = rows[idx[-2]:idx[-1]]
+idx = [i for i, r in enumerate(rows) if 'finalize' in r['Kernel_Name']]
+s = rows[idx[-2] + 1:idx[-1] + 1]
 t0 = int(s[0]['Start_Timestamp'])
 agg = {}
 end = t0
