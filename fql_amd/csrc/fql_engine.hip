@@ -15,6 +15,10 @@
 #include "fql_chain.h"
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -174,6 +178,24 @@ struct Program {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     int64_t macs = 0;
+    // threaded eager issue (run_threaded): sequence number of the run whose event record of launch i has been enqueued
+    std::unique_ptr<std::atomic<uint64_t>[]> rec;
+    size_t rec_n = 0;
+    uint64_t run_seq = 0;
+};
+
+// One host thread per extra lane for the threaded eager executor: spins for a short while after a job (back-to-back updates find it
+// hot), then sleeps on a condition variable.
+struct LaneWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::atomic<uint64_t> job{0}, done{0};
+    std::atomic<bool> stop{false};
+    Program* pr = nullptr;
+    hipStream_t s = nullptr;
+    int lane = 0;
+    std::string err;     // set by the worker when a HIP call failed during the job
 };
 
 struct PassBuf {
@@ -1294,6 +1316,7 @@ struct fql_engine {
         int maxlv = 0;
         for (const Op& op : pr.ops) maxlv = std::max(maxlv, op.level);
         pr.launches.clear();
+        pr.rec_n = 0;
         pr.two_lanes = false;
         for (bool& b : pr.lane_used) b = false;
         std::vector<int> launch_of(pr.ops.size(), -1);
@@ -1618,6 +1641,230 @@ struct fql_engine {
                             "(hipStreamEndCapture recursion); move one of the passes", a, b);
     }
 
+    // one launch of a program on stream s (tl: timeline id of the diagnostics build, -1 = none); reads engine state only
+    void issue(const Launch& L, hipStream_t s, int tl) {
+        static const int side_prio = getenv("FQL_SIDE_PRIO") ? atoi(getenv("FQL_SIDE_PRIO")) : 0;
+        switch (L.type) {
+            case OP_GEMM:
+                if (L.euler && L.kbig) hipLaunchKernelGGL((fql_gemm16_euler_kernel<true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
+                else if (L.euler) hipLaunchKernelGGL((fql_gemm16_euler_kernel<false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
+                else if (L.tmt2 && L.kbig) hipLaunchKernelGGL((fql_gemm16_kernel<true, true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
+                else if (L.tmt2) hipLaunchKernelGGL((fql_gemm16_kernel<true, false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
+                else if (L.kbig) hipLaunchKernelGGL((fql_gemm16_kernel<false, true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
+                else hipLaunchKernelGGL((fql_gemm16_kernel<false, false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
+                break;
+            case OP_GEMM64:
+                if (L.side && L.tmt2)
+                    hipLaunchKernelGGL(fql_side_big_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks,
+                                       (const WgradTask*)L.table_w, L.n_w, (const LnBwdTask*)L.table_l, L.n_l, L.tile_w, L.tile_l,
+                                       (const MiscTask*)L.table_m, L.tile_m, 0, tl);
+                else if (L.side)
+                    hipLaunchKernelGGL(fql_side_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks,
+                                       (const WgradTask*)L.table_w, L.n_w, (const LnBwdTask*)L.table_l, L.n_l, L.tile_w, L.tile_l,
+                                       (const MiscTask*)L.table_m, L.tile_m, side_prio, tl);
+                else
+                    hipLaunchKernelGGL(fql_gemm64_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
+                break;
+            case OP_WGRAD:
+                hipLaunchKernelGGL(fql_wgrad_kernel, dim3(L.grid), dim3(FQL_THREADS), 0, s, (const WgradTask*)L.table, L.ntasks);
+                break;
+            case OP_LNBWD:
+                hipLaunchKernelGGL(fql_lnbwd_kernel, dim3(L.grid), dim3(FQL_THREADS), 0, s, (const LnBwdTask*)L.table, L.ntasks);
+                break;
+            case OP_PREP:
+                { PrepArgs pa = L.op.prep; pa.tl = tl; hipLaunchKernelGGL(fql_prep_kernel, dim3((pa.B + 3) / 4), dim3(FQL_THREADS), 0, s, pa); }
+                break;
+            case OP_POSTOS:
+                hipLaunchKernelGGL(fql_post_onestep_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.postos);
+                break;
+            case OP_PEC: {
+                const PecArgs& a = L.op.pec;
+                const int T = cfg.actor_hidden[0] / 32;
+                const size_t lds = ((size_t)16 * (cfg.actor_hidden[0] + 4) + 1024 + 576 + 512 * (size_t)a.ntile) * sizeof(float);
+                if (cfg.actor_hidden[0] == 512) hipLaunchKernelGGL((fql_euler_persistent_kernel<512>), dim3(a.nteams * T), dim3(FQL_THREADS), lds, s, a);
+                else hipLaunchKernelGGL((fql_euler_persistent_kernel<256>), dim3(a.nteams * T), dim3(FQL_THREADS), lds, s, a);
+                break;
+            }
+            case OP_EULER_FIN:
+                hipLaunchKernelGGL(fql_euler_finish_kernel, dim3((L.op.ef.M * L.op.ef.ad + FQL_THREADS - 1) / FQL_THREADS), dim3(FQL_THREADS), 0, s, L.op.ef);
+                break;
+            case OP_LOSS_CRITIC:
+                hipLaunchKernelGGL(fql_loss_critic_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.lc);
+                break;
+            case OP_LOSS_Q:
+                hipLaunchKernelGGL(fql_loss_q_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.lq);
+                break;
+            case OP_LOSS_BC:
+                hipLaunchKernelGGL(fql_loss_bc_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.lb);
+                break;
+            case OP_LOSS_ACTOR:
+                hipLaunchKernelGGL(fql_loss_actor_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.la);
+                break;
+            case OP_CONV_WPREP:
+                hipLaunchKernelGGL(fql_conv_wprep_kernel, dim3(4, L.op.wprep_n), dim3(FQL_THREADS), 0, s, L.op.wprep_tasks);
+                break;
+            case OP_CONV:
+                hipLaunchKernelGGL(fql_conv3x3_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
+                break;
+            case OP_CONV_U8:
+                hipLaunchKernelGGL(fql_conv3x3_u8_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
+                break;
+            case OP_POOL: {
+                const PoolArgs& a = L.op.pool;
+                const size_t tot = (size_t)a.N * (a.H / 2) * (a.W / 2) * (a.C / 4);
+                hipLaunchKernelGGL(fql_maxpool_kernel, dim3((unsigned)((tot + FQL_THREADS - 1) / FQL_THREADS)), dim3(FQL_THREADS), 0, s, a);
+                break;
+            }
+            case OP_POOL_BWD: {
+                const PoolBwdArgs& a = L.op.poolb;
+                const size_t tot = (size_t)a.N * a.H * a.W * (a.C / 4);
+                hipLaunchKernelGGL(fql_maxpool_bwd_kernel, dim3((unsigned)((tot + FQL_THREADS - 1) / FQL_THREADS)), dim3(FQL_THREADS), 0, s, a);
+                break;
+            }
+            case OP_CONV_WGRAD:
+                hipLaunchKernelGGL(fql_conv_wgrad_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvWgradArgs*)L.table, L.ntasks);
+                break;
+            case OP_CONV_WRED:
+                hipLaunchKernelGGL(fql_conv_wgrad_reduce_kernel, dim3(L.grid), dim3(FQL_THREADS), 0, s, (const ConvWredArgs*)L.table, L.ntasks);
+                break;
+            case OP_ENC_DZ: {
+                const EncDzArgs& a = L.op.edz;
+                hipLaunchKernelGGL(fql_enc_dz_kernel, dim3((a.M * a.n + FQL_THREADS - 1) / FQL_THREADS), dim3(FQL_THREADS), 0, s, a);
+                break;
+            }
+            case OP_CHAIN: {
+                ChainArgs ca = L.op.chain; ca.tl = tl;
+                if (cfg.actor_hidden[0] == 512) hipLaunchKernelGGL((fql_chain_kernel<512>), dim3((L.op.chain.M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, ca);
+                else hipLaunchKernelGGL((fql_chain_kernel<256>), dim3((L.op.chain.M / 16) * 8), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(256), s, ca);
+                break;
+            }
+            case OP_WFRAG:
+                hipLaunchKernelGGL(fql_wfrag_kernel, dim3(wfrag_grid), dim3(FQL_THREADS), 0, s, (const WfragTask*)d_wfrag, wfrag_n, tl);
+                break;
+            case OP_ADAM: {
+                AdamArgs a{P, G, Mu, Nu, P + n_train, d_chunks, d_state, d_partials, L.op.adam_c0, (int)critic_size, cfg.lr, cfg.tau, tl};
+                hipLaunchKernelGGL(fql_adam_kernel, dim3(L.op.adam_n < 0 ? n_chunks : L.op.adam_n), dim3(FQL_THREADS), 0, s, a);
+                break;
+            }
+            case OP_FINALIZE:
+                hipLaunchKernelGGL(fql_finalize_kernel, dim3(1), dim3(FQL_THREADS), 0, s,
+                                   FinalizeArgs{d_state, d_chunks, d_partials, d_leaf_range, n_chunks, n_train_leaves, L.op.fin_mode, tl});
+                break;
+        }
+    }
+
+    // ---- threaded eager executor ---------------------------------------------------------------------------------------------
+    // The lanes of a program issued as plain launches, each lane's stream fed by a host thread of its own (lane 0 by the caller).
+    // Cross-lane dependencies: the producer records its event and then publishes the run's sequence number for that launch; the
+    // consumer's thread waits for the number (so the event it makes its stream wait on is THIS run's record), then
+    // hipStreamWaitEvent.  Nothing is captured, so the lane graph may hold edges in both directions.
+    std::unique_ptr<LaneWorker> workers[FQL_LANES];
+    std::atomic<bool> lanes_abort{false};
+
+    void run_lane(Program& pr, int lane, hipStream_t s, uint64_t seq) {
+        const bool diag = (&pr == &prog_full);
+        if (lane != 0) HIP_CHECK(hipStreamWaitEvent(s, pr.ev_fork, 0));
+        for (size_t i = 0; i < pr.launches.size(); ++i) {
+            const Launch& L = pr.launches[i];
+            if (L.lane != lane) continue;
+            for (int w : L.waits) {
+                if (!pr.launches[w].ev) continue;
+                int spins = 0;
+                while (pr.rec[w].load(std::memory_order_acquire) < seq) {
+                    if (lanes_abort.load(std::memory_order_relaxed)) throw HipError{"threaded lanes: aborted after an error on another lane"};
+                    if (++spins > 64) { __builtin_ia32_pause(); }
+                }
+                HIP_CHECK(hipStreamWaitEvent(s, pr.launches[w].ev, 0));
+            }
+            issue(L, s, diag ? (int)i : -1);
+            if (L.record_after) {
+                HIP_CHECK(hipEventRecord(L.ev, s));
+                pr.rec[i].store(seq, std::memory_order_release);
+            }
+        }
+        if (lane != 0) HIP_CHECK(hipEventRecord(pr.ev_join[lane], s));
+        HIP_CHECK(hipGetLastError());
+    }
+
+    void worker_main(LaneWorker* w) {
+        hipSetDevice(device);
+        uint64_t last = 0;
+        for (;;) {
+            uint64_t j = last;
+            for (int spin = 0; spin < 40000 && (j = w->job.load(std::memory_order_acquire)) == last && !w->stop.load(std::memory_order_relaxed); ++spin)
+                __builtin_ia32_pause();
+            if (j == last && !w->stop.load()) {
+                std::unique_lock<std::mutex> lk(w->m);
+                w->cv.wait(lk, [&] { return w->job.load(std::memory_order_acquire) != last || w->stop.load(); });
+                j = w->job.load(std::memory_order_acquire);
+            }
+            if (w->stop.load()) return;
+            try {
+                run_lane(*w->pr, w->lane, w->s, w->pr->run_seq);
+            } catch (const HipError& e) {
+                w->err = e.msg;
+                lanes_abort.store(true);
+            }
+            last = j;
+            w->done.store(j, std::memory_order_release);
+        }
+    }
+
+    void stop_workers() {
+        for (auto& w : workers) {
+            if (!w) continue;
+            w->stop.store(true);
+            { std::lock_guard<std::mutex> lk(w->m); }
+            w->cv.notify_one();
+            if (w->th.joinable()) w->th.join();
+            w.reset();
+        }
+    }
+
+    void run_threaded(Program& pr, hipStream_t s0) {
+        if (!pr.two_lanes) { run_launches(pr, s0); return; }
+        hipStream_t ls[FQL_LANES] = {s0, stream2, stream3, stream4};
+        if (pr.rec_n != pr.launches.size()) {      // first run of this program: events and sequence slots
+            pr.rec.reset(new std::atomic<uint64_t>[pr.launches.size()]);
+            for (size_t i = 0; i < pr.launches.size(); ++i) pr.rec[i].store(0);
+            pr.rec_n = pr.launches.size();
+            pr.run_seq = 0;
+            for (Launch& L : pr.launches)
+                if (L.record_after && !L.ev) HIP_CHECK(hipEventCreateWithFlags(&L.ev, hipEventDisableTiming));
+            if (!pr.ev_fork) HIP_CHECK(hipEventCreateWithFlags(&pr.ev_fork, hipEventDisableTiming));
+            for (int l = 1; l < FQL_LANES; ++l)
+                if (pr.lane_used[l] && !pr.ev_join[l]) HIP_CHECK(hipEventCreateWithFlags(&pr.ev_join[l], hipEventDisableTiming));
+        }
+        const uint64_t seq = ++pr.run_seq;
+        lanes_abort.store(false);
+        HIP_CHECK(hipEventRecord(pr.ev_fork, s0));
+        for (int l = 1; l < FQL_LANES; ++l) {
+            if (!pr.lane_used[l]) continue;
+            if (!workers[l]) {
+                workers[l].reset(new LaneWorker);
+                workers[l]->lane = l;
+                workers[l]->th = std::thread([this, w = workers[l].get()] { worker_main(w); });
+            }
+            LaneWorker* w = workers[l].get();
+            w->pr = &pr; w->s = ls[l]; w->err.clear();
+            // job numbers are per worker (programs alternate), the run's sequence number travels in the program
+            w->job.store(w->job.load(std::memory_order_relaxed) + 1, std::memory_order_release);
+            { std::lock_guard<std::mutex> lk(w->m); }
+            w->cv.notify_one();
+        }
+        std::string err0;
+        try { run_lane(pr, 0, s0, seq); } catch (const HipError& e) { err0 = e.msg; lanes_abort.store(true); }
+        for (int l = 1; l < FQL_LANES; ++l) {
+            if (!pr.lane_used[l]) continue;
+            LaneWorker* w = workers[l].get();
+            const uint64_t want = w->job.load(std::memory_order_relaxed);
+            while (w->done.load(std::memory_order_acquire) != want) __builtin_ia32_pause();
+            if (err0.empty() && !w->err.empty()) err0 = w->err;
+            if (err0.empty()) HIP_CHECK(hipStreamWaitEvent(s0, pr.ev_join[l], 0));
+        }
+        if (!err0.empty()) throw HipError{err0};
+    }
+
     // s2 != nullptr: two-stream issue (graph capture of a two-lane program); otherwise everything goes to `s0` in
     // emission order, which is a topological order of the program.
     void run_launches(Program& pr, hipStream_t s0, bool fork = false) {
@@ -1653,115 +1900,7 @@ struct fql_engine {
             if (trace_l) fprintf(stderr, "[fql] launch %d type %d lane %d waits %zu\n", (int)(&L - pr.launches.data()), (int)L.type, L.lane, L.waits.size());
             if (par)
                 for (int w : L.waits) if (pr.launches[w].ev) HIP_CHECK(hipStreamWaitEvent(s, pr.launches[w].ev, 0));
-            static const int side_prio = getenv("FQL_SIDE_PRIO") ? atoi(getenv("FQL_SIDE_PRIO")) : 0;
-            const int tl = (&pr == &prog_full) ? (int)(&L - pr.launches.data()) : -1;   // timeline id (diagnostics build)
-            switch (L.type) {
-                case OP_GEMM:
-                    if (L.euler && L.kbig) hipLaunchKernelGGL((fql_gemm16_euler_kernel<true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
-                    else if (L.euler) hipLaunchKernelGGL((fql_gemm16_euler_kernel<false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
-                    else if (L.tmt2 && L.kbig) hipLaunchKernelGGL((fql_gemm16_kernel<true, true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
-                    else if (L.tmt2) hipLaunchKernelGGL((fql_gemm16_kernel<true, false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
-                    else if (L.kbig) hipLaunchKernelGGL((fql_gemm16_kernel<false, true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
-                    else hipLaunchKernelGGL((fql_gemm16_kernel<false, false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
-                    break;
-                case OP_GEMM64:
-                    if (L.side && L.tmt2)
-                        hipLaunchKernelGGL(fql_side_big_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks,
-                                           (const WgradTask*)L.table_w, L.n_w, (const LnBwdTask*)L.table_l, L.n_l, L.tile_w, L.tile_l,
-                                           (const MiscTask*)L.table_m, L.tile_m, 0, tl);
-                    else if (L.side)
-                        hipLaunchKernelGGL(fql_side_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks,
-                                           (const WgradTask*)L.table_w, L.n_w, (const LnBwdTask*)L.table_l, L.n_l, L.tile_w, L.tile_l,
-                                           (const MiscTask*)L.table_m, L.tile_m, side_prio, tl);
-                    else
-                        hipLaunchKernelGGL(fql_gemm64_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
-                    break;
-                case OP_WGRAD:
-                    hipLaunchKernelGGL(fql_wgrad_kernel, dim3(L.grid), dim3(FQL_THREADS), 0, s, (const WgradTask*)L.table, L.ntasks);
-                    break;
-                case OP_LNBWD:
-                    hipLaunchKernelGGL(fql_lnbwd_kernel, dim3(L.grid), dim3(FQL_THREADS), 0, s, (const LnBwdTask*)L.table, L.ntasks);
-                    break;
-                case OP_PREP:
-                    { PrepArgs pa = L.op.prep; pa.tl = tl; hipLaunchKernelGGL(fql_prep_kernel, dim3((pa.B + 3) / 4), dim3(FQL_THREADS), 0, s, pa); }
-                    break;
-                case OP_POSTOS:
-                    hipLaunchKernelGGL(fql_post_onestep_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.postos);
-                    break;
-                case OP_PEC: {
-                    const PecArgs& a = L.op.pec;
-                    const int T = cfg.actor_hidden[0] / 32;
-                    const size_t lds = ((size_t)16 * (cfg.actor_hidden[0] + 4) + 1024 + 576 + 512 * (size_t)a.ntile) * sizeof(float);
-                    if (cfg.actor_hidden[0] == 512) hipLaunchKernelGGL((fql_euler_persistent_kernel<512>), dim3(a.nteams * T), dim3(FQL_THREADS), lds, s, a);
-                    else hipLaunchKernelGGL((fql_euler_persistent_kernel<256>), dim3(a.nteams * T), dim3(FQL_THREADS), lds, s, a);
-                    break;
-                }
-                case OP_EULER_FIN:
-                    hipLaunchKernelGGL(fql_euler_finish_kernel, dim3((L.op.ef.M * L.op.ef.ad + FQL_THREADS - 1) / FQL_THREADS), dim3(FQL_THREADS), 0, s, L.op.ef);
-                    break;
-                case OP_LOSS_CRITIC:
-                    hipLaunchKernelGGL(fql_loss_critic_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.lc);
-                    break;
-                case OP_LOSS_Q:
-                    hipLaunchKernelGGL(fql_loss_q_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.lq);
-                    break;
-                case OP_LOSS_BC:
-                    hipLaunchKernelGGL(fql_loss_bc_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.lb);
-                    break;
-                case OP_LOSS_ACTOR:
-                    hipLaunchKernelGGL(fql_loss_actor_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.la);
-                    break;
-                case OP_CONV_WPREP:
-                    hipLaunchKernelGGL(fql_conv_wprep_kernel, dim3(4, L.op.wprep_n), dim3(FQL_THREADS), 0, s, L.op.wprep_tasks);
-                    break;
-                case OP_CONV:
-                    hipLaunchKernelGGL(fql_conv3x3_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
-                    break;
-                case OP_CONV_U8:
-                    hipLaunchKernelGGL(fql_conv3x3_u8_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
-                    break;
-                case OP_POOL: {
-                    const PoolArgs& a = L.op.pool;
-                    const size_t tot = (size_t)a.N * (a.H / 2) * (a.W / 2) * (a.C / 4);
-                    hipLaunchKernelGGL(fql_maxpool_kernel, dim3((unsigned)((tot + FQL_THREADS - 1) / FQL_THREADS)), dim3(FQL_THREADS), 0, s, a);
-                    break;
-                }
-                case OP_POOL_BWD: {
-                    const PoolBwdArgs& a = L.op.poolb;
-                    const size_t tot = (size_t)a.N * a.H * a.W * (a.C / 4);
-                    hipLaunchKernelGGL(fql_maxpool_bwd_kernel, dim3((unsigned)((tot + FQL_THREADS - 1) / FQL_THREADS)), dim3(FQL_THREADS), 0, s, a);
-                    break;
-                }
-                case OP_CONV_WGRAD:
-                    hipLaunchKernelGGL(fql_conv_wgrad_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvWgradArgs*)L.table, L.ntasks);
-                    break;
-                case OP_CONV_WRED:
-                    hipLaunchKernelGGL(fql_conv_wgrad_reduce_kernel, dim3(L.grid), dim3(FQL_THREADS), 0, s, (const ConvWredArgs*)L.table, L.ntasks);
-                    break;
-                case OP_ENC_DZ: {
-                    const EncDzArgs& a = L.op.edz;
-                    hipLaunchKernelGGL(fql_enc_dz_kernel, dim3((a.M * a.n + FQL_THREADS - 1) / FQL_THREADS), dim3(FQL_THREADS), 0, s, a);
-                    break;
-                }
-                case OP_CHAIN: {
-                    ChainArgs ca = L.op.chain; ca.tl = tl;
-                    if (cfg.actor_hidden[0] == 512) hipLaunchKernelGGL((fql_chain_kernel<512>), dim3((L.op.chain.M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, ca);
-                    else hipLaunchKernelGGL((fql_chain_kernel<256>), dim3((L.op.chain.M / 16) * 8), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(256), s, ca);
-                    break;
-                }
-                case OP_WFRAG:
-                    hipLaunchKernelGGL(fql_wfrag_kernel, dim3(wfrag_grid), dim3(FQL_THREADS), 0, s, (const WfragTask*)d_wfrag, wfrag_n, tl);
-                    break;
-                case OP_ADAM: {
-                    AdamArgs a{P, G, Mu, Nu, P + n_train, d_chunks, d_state, d_partials, L.op.adam_c0, (int)critic_size, cfg.lr, cfg.tau, tl};
-                    hipLaunchKernelGGL(fql_adam_kernel, dim3(L.op.adam_n < 0 ? n_chunks : L.op.adam_n), dim3(FQL_THREADS), 0, s, a);
-                    break;
-                }
-                case OP_FINALIZE:
-                    hipLaunchKernelGGL(fql_finalize_kernel, dim3(1), dim3(FQL_THREADS), 0, s,
-                                       FinalizeArgs{d_state, d_chunks, d_partials, d_leaf_range, n_chunks, n_train_leaves, L.op.fin_mode, tl});
-                    break;
-            }
+            issue(L, s, (&pr == &prog_full) ? (int)(&L - pr.launches.data()) : -1);
             if (par && L.record_after) {
                 if (!L.ev) HIP_CHECK(hipEventCreateWithFlags(&L.ev, hipEventDisableTiming));
                 HIP_CHECK(hipEventRecord(L.ev, s));
@@ -2650,19 +2789,28 @@ int fql_create(const fql_config* cfg, uint64_t seed, fql_handle* out) {
             delete h;
             return FQL_E_NODEVICE;
         }
-        // (stream priorities were tried for the lanes: no gain with two streams, a 4x slowdown with three)
+        // (stream priorities were tried for the graph lanes in round 1: no gain with two streams, a 4x slowdown with three)
         h->num_cus = prop.multiProcessorCount;
         if (const char* cm = getenv("FQL_CUMASK")) {  // experiment: disjoint CU sets for the two lanes (host-launched lane graphs)
             const uint32_t m0 = (uint32_t)strtoul(cm, nullptr, 16);
             std::vector<uint32_t> a(8, m0), b(8, ~m0);
             HIP_CHECK(hipExtStreamCreateWithCUMask(&h->stream, 8, a.data()));
             HIP_CHECK(hipExtStreamCreateWithCUMask(&h->stream2, 8, b.data()));
+            HIP_CHECK(hipExtStreamCreateWithCUMask(&h->stream3, 8, b.data()));
+            HIP_CHECK(hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking));
         } else {
-        HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-        HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+            // FQL_LANE_PRIO=1 (experiment): the engine's own stream at the highest queue priority, the extra lanes at the lowest, so the
+            // latency-bound Euler chain on lane 0 gets free CU slots before the throughput work of the other lanes
+            int lo = 0, hi = 0;
+            HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            const int mode = getenv("FQL_LANE_PRIO") ? atoi(getenv("FQL_LANE_PRIO")) : 0;
+            const int p0 = (mode & 1) ? hi : 0, px = (mode & 2) ? lo : 0;
+            if (getenv("FQL_TRACE")) fprintf(stderr, "[fql] stream priority range lo %d hi %d -> lane0 %d others %d\n", lo, hi, p0, px);
+            HIP_CHECK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, p0));
+            HIP_CHECK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, px));
+            HIP_CHECK(hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, px));
+            HIP_CHECK(hipStreamCreateWithPriority(&h->stream4, hipStreamNonBlocking, px));
         }
-        HIP_CHECK(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
-        HIP_CHECK(hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking));
         h->build_nets();
         HIP_CHECK(hipMalloc((void**)&h->P, h->n_total * sizeof(float)));
         HIP_CHECK(hipMalloc((void**)&h->G, h->n_train * sizeof(float)));
@@ -2699,6 +2847,7 @@ int fql_create(const fql_config* cfg, uint64_t seed, fql_handle* out) {
 
 int fql_destroy(fql_handle h) {
     if (!h) return FQL_OK;
+    h->stop_workers();
     if (h->stream) hipStreamSynchronize(h->stream);
     hipDeviceSynchronize();
     h->free_workspace();
@@ -2805,7 +2954,9 @@ static void run_program(fql_handle h, Program& pr, hipStream_t s) {
     static const bool no_graph = getenv("FQL_NO_GRAPH") != nullptr;
     static const bool eager_lanes = getenv("FQL_NO_GRAPH") && atoi(getenv("FQL_NO_GRAPH")) == 2;   // eager launches on the lane streams
     static const bool split_default = getenv("FQL_SPLIT_DEFAULT") != nullptr;  // experiment: host-launched lane graphs
-    if (eager_lanes) h->run_launches(pr, s, true);
+    static const bool threaded = getenv("FQL_NO_GRAPH") && atoi(getenv("FQL_NO_GRAPH")) == 3;      // ... one host thread per lane
+    if (threaded) h->run_threaded(pr, s);
+    else if (eager_lanes) h->run_launches(pr, s, true);
     else if (no_graph) h->run_launches(pr, s);
     else if (split_default && (&pr == &h->prog_fwdbwd) && h->split_ok && s != h->stream2) h->launch_split(s, h->stream2);
     else HIP_CHECK(hipGraphLaunch(pr.exec, s));
