@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
     const size_t lds = ((size_t)16 * tmt * (K + 4) + 1024 * tmt) * 4;
     hipGraph_t g; hipGraphExec_t ge;
     CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < 96; ++i) hipLaunchKernelGGL((fql_gemm16_kernel<true, false>), dim3(grid), dim3(256), lds, s, tb + (i % 8), 1);
+    for (int i = 0; i < 96; ++i) hipLaunchKernelGGL((fql_gemm16_kernel<true, false>), dim3(grid), dim3(256), lds, s, tb + (i % 8), 1, -1);
     CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
     for (int i = 0; i < 20; ++i) CK(hipGraphLaunch(ge, s));
     CK(hipStreamSynchronize(s));
