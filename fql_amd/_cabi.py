@@ -70,6 +70,13 @@ SYMBOLS = {
     'fql_dataset_upload': (_I, [_VP, _I64, _I64, _VP, _VP, _VP, _VP, _VP]),
     'fql_dataset_add': (_I, [_VP, _VP, _VP, _F, _F, _VP]),
     'fql_dataset_size': (_I, [_VP, C.POINTER(_I64), C.POINTER(_I64)]),
+    'fql_dataset_reserve': (_I, [_VP, _I64]),
+    'fql_dataset_add_frames': (_I, [_VP, _VP, _VP, _VP, _F, _F]),
+    'fql_replay_create': (_I, [_VP, _I64]),
+    'fql_replay_add': (_I, [_VP, _VP, _VP, _F, _F, _VP]),
+    'fql_replay_add_frames': (_I, [_VP, _VP, _VP, _VP, _F, _F]),
+    'fql_replay_size': (_I, [_VP, C.POINTER(_I64), C.POINTER(_I64)]),
+    'fql_update_balanced': (_I, [_VP, _VP, _VP, _VP, _I, C.POINTER(FqlNoise), _VP, _VP]),
     'fql_update_from_dataset': (_I, [_VP, _VP, _I, _I64, _I64, C.POINTER(FqlNoise), _VP, _VP]),
     'fql_update_from_dataset_begin': (_I, [_VP, _VP, _I, _I64, _I64, C.POINTER(FqlNoise), _VP]),
     'fql_dataset_upload_frames': (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _I, _F]),

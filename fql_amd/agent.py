@@ -336,10 +336,58 @@ class FQLAgent:
         args = [_Arg(dataset[k]) for k in BATCH_KEYS]
         self._check(self._lib.fql_dataset_upload(self._h, n, cap, *[a.ptr for a in args]))
 
-    def add_transition(self, transition):
-        o = _Arg(transition['observations']); a = _Arg(transition['actions']); no = _Arg(transition['next_observations'])
-        self._check(self._lib.fql_dataset_add(self._h, o.ptr, a.ptr, float(transition['rewards']),
-                                              float(transition['masks']), no.ptr))
+    def reserve_dataset(self, capacity: int):
+        """ReplayBuffer.create_from_initial_dataset(dataset, size) (utils/datasets.py:457-473, main.py:111-115): the uploaded dataset
+        becomes a ring of `capacity` rows (state or uint8 frames); `add_transition` then inserts at the pointer."""
+        self._check(self._lib.fql_dataset_reserve(self._h, int(capacity)))
+
+    def create_replay_buffer(self, size: int):
+        """ReplayBuffer.create(example_transition, size) (utils/datasets.py:441-455; main.py:106-109): an empty device ring beside the
+        training dataset, the second source of `update_balanced`."""
+        self._check(self._lib.fql_replay_create(self._h, int(size)))
+
+    def add_transition(self, transition, replay: bool = False):
+        """ReplayBuffer.add_transition (utils/datasets.py:483-491) into the dataset ring (replay=False: the dataset IS the replay
+        buffer, main.py:111-115) or into the separate replay ring (replay=True, balanced sampling).  Visual agents pass single uint8
+        frames [H, W, C / frame_stack] as observations / next_observations."""
+        a = _Arg(transition['actions'])
+        r, m = float(transition['rewards']), float(transition['masks'])
+        if len(self.config['ob_dims']) == 3:
+            fr = _Arg(transition['observations'], u8=True); nf = _Arg(transition['next_observations'], u8=True)
+            f = self._lib.fql_replay_add_frames if replay else self._lib.fql_dataset_add_frames
+            self._check(f(self._h, fr.ptr, nf.ptr, a.ptr, r, m))
+            return
+        o = _Arg(transition['observations']); no = _Arg(transition['next_observations'])
+        f = self._lib.fql_replay_add if replay else self._lib.fql_dataset_add
+        self._check(f(self._h, o.ptr, a.ptr, r, m, no.ptr))
+
+    def replay_size(self):
+        s, p = C.c_int64(), C.c_int64()
+        self._check(self._lib.fql_replay_size(self._h, C.byref(s), C.byref(p)))
+        return int(s.value), int(p.value)
+
+    def update_balanced(self, batch_size=None, idxs=None, noise=None, want_info=False, stream=None, crop_froms=None):
+        """main.py:255-259 + :216 on the device: concat(train_dataset.sample(B // 2), replay_buffer.sample(B // 2)) -> agent.update.
+        `idxs` = (dataset_idxs, replay_idxs), B // 2 each, or None (engine RNG)."""
+        B = int(batch_size or self.config['batch_size'])
+        self._ensure_batch(B)
+        nz, nargs = self._noise_args(noise, B)
+        ia = ib = None
+        keep = None
+        if idxs is not None:
+            ka = np.ascontiguousarray(idxs[0], dtype=np.int64); kb = np.ascontiguousarray(idxs[1], dtype=np.int64)
+            if ka.size != B // 2 or kb.size != B // 2:
+                raise ValueError('idxs must be two arrays of batch_size // 2 entries')
+            ia, ib, keep = ka.ctypes.data, kb.ctypes.data, (ka, kb)
+        cp = None
+        if crop_froms is not None:
+            ck = np.ascontiguousarray(crop_froms, dtype=np.int32)
+            if ck.shape != (B, 2):
+                raise ValueError('crop_froms must be [batch_size, 2]')
+            cp, keep = ck.ctypes.data, (keep, ck)
+        self._check(self._lib.fql_update_balanced(self._h, ia, ib, cp, B, C.byref(nz) if nz else None, None, stream))
+        self._keep = (keep, nargs)
+        return self, (self._lazy_info(stream) if want_info else None)
 
     def dataset_size(self):
         s, p = C.c_int64(), C.c_int64()

@@ -519,6 +519,10 @@ struct ImgGatherArgs {
     unsigned char* obs;                // [B,H,W,k C]
     unsigned char* nobs;
     int B, H, W, C, k, pad;
+    // balanced sampling (main.py:255-259): rows [split, B) read the replay ring's frames; 0 = one source
+    int split;
+    const unsigned char* frames2;
+    const unsigned char* next_frames2;
 };
 __global__ __launch_bounds__(FQL_THREADS) void fql_img_gather_kernel(const ImgGatherArgs P) {
     const int KC = P.k * P.C;
@@ -540,9 +544,11 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_img_gather_kernel(const ImgGa
     const size_t img = (size_t)P.H * P.W * P.C;
     // frame f of obs is ob[max(t - (k-1-f), init)]; frame f of next is the same list shifted by one with next_ob[t] last
     const int64_t so = max(t - (P.k - 1 - f), i0);
-    P.obs[e] = P.frames[(size_t)so * img + pix];
-    if (f == P.k - 1) P.nobs[e] = P.next_frames[(size_t)t * img + pix];
-    else P.nobs[e] = P.frames[(size_t)max(t - (P.k - 2 - f), i0) * img + pix];
+    const bool second = P.split > 0 && b >= P.split;
+    const unsigned char* fr = second ? P.frames2 : P.frames;
+    P.obs[e] = fr[(size_t)so * img + pix];
+    if (f == P.k - 1) P.nobs[e] = (second ? P.next_frames2 : P.next_frames)[(size_t)t * img + pix];
+    else P.nobs[e] = fr[(size_t)max(t - (P.k - 2 - f), i0) * img + pix];
 }
 
 // index draw (utils/datasets.py:64-66), episode starts and crop offsets (utils/datasets.py:102-112) of one batch
@@ -558,18 +564,25 @@ struct ImgIndexArgs {
     int64_t* idx;             // out [B]
     int64_t* init;            // out [B]
     int* crop;                // out [B][2]
+    // balanced sampling: rows [split, B) index the replay ring (its own range, episode starts and augmentation coin:
+    // train_dataset.sample and replay_buffer.sample are two calls, main.py:257-258); 0 = one source
+    int split;
+    const int64_t* ds_init2;
+    int64_t lo2, span2;
 };
 __global__ __launch_bounds__(FQL_THREADS) void fql_img_index_kernel(const ImgIndexArgs P) {
     const int b = blockIdx.x * FQL_THREADS + threadIdx.x;
     if (b >= P.B) return;
     const uint64_t step = P.st->rng_step;
     const uint64_t key = P.key ^ (P.st->rng_stream * 0x9E3779B97F4A7C15ull);
-    int64_t i = P.idx_in ? P.idx_in[b] : P.lo + (int64_t)(((uint64_t)rng_u32(key, step, 7u, (uint32_t)b) * (uint64_t)P.span) >> 32);
+    const bool second = P.split > 0 && b >= P.split;
+    const uint64_t u = rng_u32(key, step, 7u, (uint32_t)b);
+    int64_t i = P.idx_in ? P.idx_in[b] : (second ? P.lo2 + (int64_t)((u * (uint64_t)P.span2) >> 32) : P.lo + (int64_t)((u * (uint64_t)P.span) >> 32));
     P.idx[b] = i;
-    P.init[b] = P.ds_init[i];
+    P.init[b] = (second ? P.ds_init2 : P.ds_init)[i];
     int cy = P.pad, cx = P.pad;   // crop_from == padding: the identity slice
     if (P.crop_in) { cy = P.crop_in[2 * b]; cx = P.crop_in[2 * b + 1]; }
-    else if (P.p_aug > 0.f && rng_uniform(key, step, 8u, 0u) < P.p_aug) {   // ONE coin per batch (utils/datasets.py:90-92)
+    else if (P.p_aug > 0.f && rng_uniform(key, step, 8u, second ? 1u : 0u) < P.p_aug) {   // ONE coin per sample() call (utils/datasets.py:90-92)
         const uint32_t w = 2u * (uint32_t)P.pad + 1u;
         cy = (int)(((uint64_t)rng_u32(key, step, 9u, (uint32_t)b) * w) >> 32);
         cx = (int)(((uint64_t)rng_u32(key, step, 10u, (uint32_t)b) * w) >> 32);

@@ -307,6 +307,11 @@ struct fql_engine {
     int64_t* ds_init = nullptr;
     int ds_fs = 0;
     float ds_paug = 0.f;
+    // replay ring beside the training dataset (balanced sampling, main.py:106-109,255-259): same row layout, starts empty
+    float *rb_obs = nullptr, *rb_act = nullptr, *rb_rew = nullptr, *rb_mask = nullptr, *rb_nobs = nullptr;
+    unsigned char *rb_frames = nullptr, *rb_next_frames = nullptr;
+    int64_t* rb_init = nullptr;
+    int64_t rb_size = 0, rb_cap = 0, rb_ptr = 0;
     int64_t* in_init = nullptr;   // [B] workspace
     int *in_crop = nullptr, *in_crop_user = nullptr;  // [B][2]
 
@@ -2574,14 +2579,47 @@ struct fql_engine {
         drain_staging(s);
         set_source(d, s);
     }
+    // indices of a balanced batch into one device array: rows [0, split) index the dataset, rows [split, B) the replay ring
+    const int64_t* stage_two_idx(const int64_t* a, const int64_t* b, int split, int64_t* dst, hipStream_t s) {
+        if (!a && !b) return nullptr;
+        if (!a || !b) throw Invalid{"balanced sampling: give both index arrays or neither"};
+        HIP_CHECK(hipMemcpyAsync(dst, a, (size_t)split * sizeof(int64_t), hipMemcpyDefault, s));
+        HIP_CHECK(hipMemcpyAsync(dst + split, b, (size_t)(B - split) * sizeof(int64_t), hipMemcpyDefault, s));
+        if (!is_device_ptr(a) || !is_device_ptr(b)) staged_host = true;
+        return dst;
+    }
+    // main.py:255-259: batch = concat(train_dataset.sample(B // 2), replay_buffer.sample(B // 2)), gathered on the device
+    void source_balanced(const int64_t* idx_ds, const int64_t* idx_rb, const int32_t* crop, int batch, const fql_noise* nz, hipStream_t s) {
+        if (batch != B) invalid("batch_size %d does not match the engine's workspace (%d)", batch, B);
+        if (B % 2) invalid("balanced sampling draws batch_size // 2 rows from each source: batch_size %d must be even", B);
+        if (ds_size <= 0 || !(visual ? (void*)ds_frames : (void*)ds_obs)) throw Invalid{"balanced sampling: no training dataset uploaded"};
+        if (rb_cap <= 0) throw Invalid{"balanced sampling: no replay ring (fql_replay_create)"};
+        if (rb_size <= 0) throw Invalid{"balanced sampling: the replay ring is empty (the reference would draw randint(0), a ValueError)"};
+        const int split = B / 2;
+        if (visual) { source_from_frames(idx_ds, crop, batch, 0, 0, nz, s, split, idx_rb); return; }
+        SrcDesc d{};
+        d.obs = ds_obs; d.act = ds_act; d.rew = ds_rew; d.mask = ds_mask; d.nobs = ds_nobs;
+        d.obs2 = rb_obs; d.act2 = rb_act; d.rew2 = rb_rew; d.mask2 = rb_mask; d.nobs2 = rb_nobs;
+        d.split = split;
+        d.idx = stage_two_idx(idx_ds, idx_rb, split, in_idx, s);
+        if (!d.idx) { d.use_rng_idx = 1; d.lo = 0; d.span = ds_size; d.lo2 = 0; d.span2 = rb_size; }
+        fill_noise(d, nz, s);
+        d.advance = 1;
+        drain_staging(s);
+        set_source(d, s);
+    }
     // Dataset.sample for image datasets (utils/datasets.py:68-92): indices, frame stacking, random crop -> img_all, on the device
-    void source_from_frames(const int64_t* idx, const int32_t* crop, int batch, int64_t lo, int64_t hi, const fql_noise* nz, hipStream_t s) {
+    void source_from_frames(const int64_t* idx, const int32_t* crop, int batch, int64_t lo, int64_t hi, const fql_noise* nz, hipStream_t s,
+                            int split = 0, const int64_t* idx_rb = nullptr) {
         if (batch != B) invalid("batch_size %d does not match the engine's workspace (%d)", batch, B);
         if (!visual || !ds_frames || ds_size <= 0) throw Invalid{"no frames dataset uploaded (fql_dataset_upload_frames)"};
         if (lo == 0 && hi == 0) hi = ds_size;
         if (lo < 0 || hi > ds_size || lo >= hi) invalid("bad sampling range [%lld, %lld) for dataset of %lld rows", (long long)lo, (long long)hi, (long long)ds_size);
         const int64_t* idx_dev = nullptr;
-        if (idx) {
+        if (split > 0) {
+            if (!rb_frames) throw Invalid{"balanced sampling: the replay ring holds no frames"};
+            idx_dev = stage_two_idx(idx, idx_rb, split, in_idx + B, s);
+        } else if (idx) {
             if (is_device_ptr(idx)) idx_dev = idx;
             else {
                 HIP_CHECK(hipMemcpyAsync(in_idx + B, idx, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, s));   // second half of in_idx
@@ -2598,17 +2636,19 @@ struct fql_engine {
                 crop_dev = in_crop_user;
             }
         }
-        ImgIndexArgs ia{idx_dev, crop_dev, ds_init, d_state, seed, lo, hi - lo, ds_paug, B, 3, in_idx, in_init, in_crop};
+        ImgIndexArgs ia{idx_dev, crop_dev, ds_init, d_state, seed, lo, hi - lo, ds_paug, B, 3, in_idx, in_init, in_crop,
+                        split, rb_init, 0, rb_size};
         hipLaunchKernelGGL(fql_img_index_kernel, dim3((B + FQL_THREADS - 1) / FQL_THREADS), dim3(FQL_THREADS), 0, s, ia);
         const size_t ib = (size_t)cfg.img_h * cfg.img_w * cfg.img_c;
         ImgGatherArgs ga{ds_frames, ds_next_frames, in_idx, in_init, in_crop, img_all, img_all + (size_t)B * ib,
-                         B, cfg.img_h, cfg.img_w, cfg.img_c / ds_fs, ds_fs, 3};
+                         B, cfg.img_h, cfg.img_w, cfg.img_c / ds_fs, ds_fs, 3, split, rb_frames, rb_next_frames};
         const size_t tot = (size_t)B * ib;
         hipLaunchKernelGGL(fql_img_gather_kernel, dim3((unsigned)((tot + FQL_THREADS - 1) / FQL_THREADS)), dim3(FQL_THREADS), 0, s, ga);
         HIP_CHECK(hipGetLastError());
         SrcDesc d{};
         d.act = ds_act; d.rew = ds_rew; d.mask = ds_mask;
         d.idx = in_idx;
+        if (split > 0) { d.split = split; d.act2 = rb_act; d.rew2 = rb_rew; d.mask2 = rb_mask; }
         fill_noise(d, nz, s);
         d.advance = 1;
         drain_staging(s);
@@ -2730,6 +2770,44 @@ static const char* k_info_names[FQL_NUM_INFO] = {
     "critic/critic_loss", "critic/q_mean", "critic/q_max", "critic/q_min", "actor/actor_loss",
     "actor/bc_flow_loss", "actor/distill_loss", "actor/q_loss", "actor/q", "actor/mse",
     "grad/max", "grad/min", "grad/norm"};
+
+// ---- online fine-tuning: ring capacity, uint8 ring insert, the replay ring of balanced sampling ---------------------------------
+namespace {
+// copy `rows` rows of `w` elements into a fresh zero-filled allocation of `cap` rows; frees the old one
+template <typename T>
+void regrow(T*& p, int64_t rows, int64_t cap, size_t w) {
+    T* q = nullptr;
+    HIP_CHECK(hipMalloc((void**)&q, (size_t)cap * w * sizeof(T)));
+    HIP_CHECK(hipMemset(q, 0, (size_t)cap * w * sizeof(T)));
+    if (p && rows > 0) HIP_CHECK(hipMemcpy(q, p, (size_t)rows * w * sizeof(T), hipMemcpyDeviceToDevice));
+    if (p) hipFree(p);
+    p = q;
+}
+}  // namespace
+
+// one transition into row `pos` of a ring: the float fields through the staging row + fql_dataset_add_kernel, frames as two byte copies
+static void ring_insert(fql_handle h, float* obs, float* act, float* rew, float* mask, float* nobs, unsigned char* frames,
+                        unsigned char* next_frames, int64_t pos, const float* ob, const float* ac, float reward, float m,
+                        const float* nob, const uint8_t* frame, const uint8_t* next_frame) {
+    const int od = frames ? 0 : h->cfg.obs_dim, ad = h->cfg.act_dim;   // frames rings keep no float observations
+    if (od > 1024) invalid("obs_dim too large for the ring-insert kernel");
+    if (!h->ds_row) HIP_CHECK(hipMalloc((void**)&h->ds_row, (size_t)(2 * h->cfg.obs_dim + ad + 2) * sizeof(float)));
+    std::vector<float> row(2 * od + ad + 2);
+    if (od) std::memcpy(row.data(), ob, od * sizeof(float));
+    std::memcpy(row.data() + od, ac, ad * sizeof(float));
+    row[od + ad] = reward; row[od + ad + 1] = m;
+    if (od) std::memcpy(row.data() + od + ad + 2, nob, od * sizeof(float));
+    HIP_CHECK(hipMemcpyAsync(h->ds_row, row.data(), row.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(fql_dataset_add_kernel, dim3(1), dim3(std::max(64, pad16(std::max(od, ad)))), 0, h->stream, obs, act, rew, mask, nobs,
+                       h->ds_row, pos, od, ad);
+    HIP_CHECK(hipGetLastError());
+    if (frames) {
+        const size_t fb = (size_t)h->cfg.img_h * h->cfg.img_w * (h->cfg.img_c / h->ds_fs);
+        HIP_CHECK(hipMemcpyAsync(frames + (size_t)pos * fb, frame, fb, hipMemcpyDefault, h->stream));
+        HIP_CHECK(hipMemcpyAsync(next_frames + (size_t)pos * fb, next_frame, fb, hipMemcpyDefault, h->stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(h->stream));   // the caller's buffers are borrowed for the call only
+}
 
 extern "C" {
 
@@ -2860,6 +2938,8 @@ int fql_destroy(fql_handle h) {
     for (auto& e : h->info_ev) if (e) hipEventDestroy(e);
     hipFree(h->ds_obs); hipFree(h->ds_act); hipFree(h->ds_rew); hipFree(h->ds_mask); hipFree(h->ds_nobs); hipFree(h->ds_row);
     hipFree(h->ds_frames); hipFree(h->ds_next_frames); hipFree(h->ds_init);
+    hipFree(h->rb_obs); hipFree(h->rb_act); hipFree(h->rb_rew); hipFree(h->rb_mask); hipFree(h->rb_nobs);
+    hipFree(h->rb_frames); hipFree(h->rb_next_frames); hipFree(h->rb_init);
     for (void* q : h->enc_allocs) hipFree(q);
     for (void* q : h->chain_allocs) hipFree(q);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -3091,6 +3171,109 @@ int fql_dataset_size(fql_handle h, int64_t* size, int64_t* pointer) {
     if (pointer) *pointer = h->ds_ptr;
     return FQL_OK;
 }
+// ---- online fine-tuning: ring capacity, uint8 ring insert, the replay ring of balanced sampling (helpers above extern "C")
+int fql_dataset_reserve(fql_handle h, int64_t capacity) {
+    if (!h) return FQL_E_INVALID;
+    FQL_TRY(h, {
+        const bool fr = h->visual;
+        if (!(fr ? (void*)h->ds_frames : (void*)h->ds_obs)) throw Invalid{"fql_dataset_reserve: no dataset uploaded"};
+        if (capacity < h->ds_cap) invalid("fql_dataset_reserve: capacity %lld below the current %lld rows", (long long)capacity, (long long)h->ds_cap);
+        if (capacity == h->ds_cap) return FQL_OK;
+        HIP_CHECK(hipDeviceSynchronize());
+        const int od = h->cfg.obs_dim, ad = h->cfg.act_dim;
+        const int64_t rows = h->ds_cap;
+        regrow(h->ds_act, rows, capacity, ad); regrow(h->ds_rew, rows, capacity, 1); regrow(h->ds_mask, rows, capacity, 1);
+        if (fr) {
+            const size_t fb = (size_t)h->cfg.img_h * h->cfg.img_w * (h->cfg.img_c / h->ds_fs);
+            regrow(h->ds_frames, rows, capacity, fb); regrow(h->ds_next_frames, rows, capacity, fb);
+            // Dataset.__init__ computes initial_locs once (utils/datasets.py:58-62); rows inserted later fall behind the LAST initial
+            // location of the initial data (searchsorted(..., side='right') - 1, utils/datasets.py:75) - kept as the reference has it
+            std::vector<int64_t> init((size_t)capacity);
+            HIP_CHECK(hipMemcpy(init.data(), h->ds_init, (size_t)rows * sizeof(int64_t), hipMemcpyDeviceToHost));
+            int64_t last = 0;
+            for (int64_t i = 0; i < rows; ++i) last = std::max(last, init[i]);
+            for (int64_t i = rows; i < capacity; ++i) init[i] = last;
+            hipFree(h->ds_init); h->ds_init = nullptr;
+            HIP_CHECK(hipMalloc((void**)&h->ds_init, (size_t)capacity * sizeof(int64_t)));
+            HIP_CHECK(hipMemcpy(h->ds_init, init.data(), (size_t)capacity * sizeof(int64_t), hipMemcpyHostToDevice));
+        } else {
+            regrow(h->ds_obs, rows, capacity, od); regrow(h->ds_nobs, rows, capacity, od);
+        }
+        h->ds_cap = capacity;
+        h->ds_ptr = h->ds_size % capacity;
+        h->src_valid = false;
+    });
+}
+int fql_dataset_add_frames(fql_handle h, const uint8_t* frame, const uint8_t* next_frame, const float* ac, float reward, float mask) {
+    if (!h) return FQL_E_INVALID;
+    FQL_TRY(h, {
+        if (!h->visual || !h->ds_frames) throw Invalid{"no frames dataset allocated (fql_dataset_upload_frames)"};
+        if (!frame || !next_frame || !ac) invalid("transition pointers must not be NULL");
+        ring_insert(h, nullptr, h->ds_act, h->ds_rew, h->ds_mask, nullptr, h->ds_frames, h->ds_next_frames, h->ds_ptr, nullptr, ac, reward, mask,
+                    nullptr, frame, next_frame);
+        h->ds_ptr = (h->ds_ptr + 1) % h->ds_cap;          // utils/datasets.py:489-491
+        h->ds_size = std::max(h->ds_ptr, h->ds_size);
+    });
+}
+int fql_replay_create(fql_handle h, int64_t capacity) {
+    if (!h) return FQL_E_INVALID;
+    FQL_TRY(h, {
+        if (capacity < 1) invalid("fql_replay_create: capacity %lld", (long long)capacity);
+        if (h->visual && !h->ds_frames) throw Invalid{"fql_replay_create: upload the frames dataset first (frame_stack and p_aug are shared, main.py:117-120)"};
+        HIP_CHECK(hipDeviceSynchronize());
+        const int od = h->cfg.obs_dim, ad = h->cfg.act_dim;
+        regrow(h->rb_act, 0, capacity, ad); regrow(h->rb_rew, 0, capacity, 1); regrow(h->rb_mask, 0, capacity, 1);
+        if (h->visual) {
+            const size_t fb = (size_t)h->cfg.img_h * h->cfg.img_w * (h->cfg.img_c / h->ds_fs);
+            regrow(h->rb_frames, 0, capacity, fb); regrow(h->rb_next_frames, 0, capacity, fb);
+            regrow(h->rb_init, 0, capacity, 1);   // ReplayBuffer.create: terminals all zero => initial_locs = [0] (utils/datasets.py:58-62)
+        } else {
+            regrow(h->rb_obs, 0, capacity, od); regrow(h->rb_nobs, 0, capacity, od);
+        }
+        h->rb_cap = capacity; h->rb_size = 0; h->rb_ptr = 0;
+        h->src_valid = false;
+    });
+}
+int fql_replay_add(fql_handle h, const float* ob, const float* ac, float reward, float mask, const float* nob) {
+    if (!h) return FQL_E_INVALID;
+    FQL_TRY(h, {
+        if (h->rb_cap <= 0 || h->visual) throw Invalid{"fql_replay_add: no state replay ring (fql_replay_create; frames agents use fql_replay_add_frames)"};
+        if (!ob || !ac || !nob) invalid("transition pointers must not be NULL");
+        ring_insert(h, h->rb_obs, h->rb_act, h->rb_rew, h->rb_mask, h->rb_nobs, nullptr, nullptr, h->rb_ptr, ob, ac, reward, mask, nob, nullptr, nullptr);
+        h->rb_ptr = (h->rb_ptr + 1) % h->rb_cap;
+        h->rb_size = std::max(h->rb_ptr, h->rb_size);
+    });
+}
+int fql_replay_add_frames(fql_handle h, const uint8_t* frame, const uint8_t* next_frame, const float* ac, float reward, float mask) {
+    if (!h) return FQL_E_INVALID;
+    FQL_TRY(h, {
+        if (h->rb_cap <= 0 || !h->visual) throw Invalid{"fql_replay_add_frames: no frames replay ring (fql_replay_create on a frames agent)"};
+        if (!frame || !next_frame || !ac) invalid("transition pointers must not be NULL");
+        ring_insert(h, nullptr, h->rb_act, h->rb_rew, h->rb_mask, nullptr, h->rb_frames, h->rb_next_frames, h->rb_ptr, nullptr, ac, reward, mask,
+                    nullptr, frame, next_frame);
+        h->rb_ptr = (h->rb_ptr + 1) % h->rb_cap;
+        h->rb_size = std::max(h->rb_ptr, h->rb_size);
+    });
+}
+int fql_replay_size(fql_handle h, int64_t* size, int64_t* pointer) {
+    if (!h) return FQL_E_INVALID;
+    if (size) *size = h->rb_size;
+    if (pointer) *pointer = h->rb_ptr;
+    return FQL_OK;
+}
+int fql_update_balanced(fql_handle h, const int64_t* idx_dataset, const int64_t* idx_replay, const int32_t* crop_froms, int batch_size,
+                        const fql_noise* noise, float* info13, void* stream) {
+    if (!h) return FQL_E_INVALID;
+    if (h->began) { h->err = "fql_update_balanced between fql_update_begin and fql_update_end"; return FQL_E_STATE; }
+    FQL_TRY(h, {
+        hipStream_t s = pick(h, stream);
+        h->source_balanced(idx_dataset, idx_replay, crop_froms, batch_size, noise, s);
+        if (h->prog_full.exec) run_program(h, h->prog_full, s);
+        else { run_program(h, h->prog_fwdbwd, s); run_program(h, h->prog_opt, s); }
+        h->finish_info(info13, FQL_NUM_INFO, s);
+    });
+}
+
 int fql_update_from_dataset_begin(fql_handle h, const int64_t* idx, int batch_size, int64_t lo, int64_t hi,
                                   const fql_noise* noise, void* stream) {
     if (!h) return FQL_E_INVALID;

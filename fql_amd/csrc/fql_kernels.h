@@ -1385,6 +1385,11 @@ struct SrcDesc {  // where the batch comes from; rewritten by the host only when
     int64_t lo, span;    // RNG index range [lo, lo+span) when idx == null and use_rng_idx
     int use_rng_idx;
     int advance;         // 1: this launch advances rng_step/adam bookkeeping (update), 0: loss-only
+    // balanced sampling (main.py:255-259): batch rows [split, B) come from a second set of arrays (the replay ring); 0 = one source.
+    // idx (when given) holds indices into the first source for rows < split and into the second for the rest.
+    int split;
+    const float *obs2, *act2, *rew2, *mask2, *nobs2;
+    int64_t lo2, span2;
 };
 
 struct PrepArgs {
@@ -1415,13 +1420,17 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_prep_kernel(PrepArgs P) {
     const uint64_t step = P.st->rng_step;
     const uint64_t key = P.key ^ (P.st->rng_stream * 0x9E3779B97F4A7C15ull);   // same create seed on every rank, different draws
     int64_t src = b;
+    const bool second = S.split > 0 && b >= S.split;   // the replay half of a balanced batch
     if (S.idx) src = S.idx[b];
-    else if (S.use_rng_idx) src = S.lo + (int64_t)(((uint64_t)rng_u32(key, step, 7u, (uint32_t)b) * (uint64_t)S.span) >> 32);
+    else if (S.use_rng_idx) {
+        const uint64_t u = rng_u32(key, step, 7u, (uint32_t)b);
+        src = second ? S.lo2 + (int64_t)((u * (uint64_t)S.span2) >> 32) : S.lo + (int64_t)((u * (uint64_t)S.span) >> 32);
+    }
     const int od = P.od, ad = P.ad, B = P.B;
     const bool vis = P.E_c != nullptr;
-    const float* obs = vis ? nullptr : S.obs + (size_t)src * od;
-    const float* nobs = vis ? nullptr : S.nobs + (size_t)src * od;
-    const float* act = S.act + (size_t)src * ad;
+    const float* obs = vis ? nullptr : (second ? S.obs2 : S.obs) + (size_t)src * od;
+    const float* nobs = vis ? nullptr : (second ? S.nobs2 : S.nobs) + (size_t)src * od;
+    const float* act = (second ? S.act2 : S.act) + (size_t)src * ad;
     const float tt = S.t ? S.t[b] : rng_uniform(key, step, 3u, (uint32_t)b);
     const int maxw = P.inp_c > P.inp_b ? P.inp_c : P.inp_b;
     for (int j = lane; j < maxw; j += 64) {
@@ -1467,8 +1476,8 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_prep_kernel(PrepArgs P) {
         }
     }
     if (lane == 0 && P.part != 1) {
-        P.w_rew[b] = S.rew[src];
-        P.w_mask[b] = S.mask[src];
+        P.w_rew[b] = (second ? S.rew2 : S.rew)[src];
+        P.w_mask[b] = (second ? S.mask2 : S.mask)[src];
     }
 }
 

@@ -135,19 +135,34 @@ class ReplayBuffer(Dataset):
         self.pointer = 0
 
     def add_transition(self, transition):
-        """utils/datasets.py:483-491 (ring insert; size = max(pointer, size), verbatim)."""
+        """utils/datasets.py:483-491 (ring insert; size = max(pointer, size), verbatim); mirrored into the device ring when attached."""
         for k, v in self.items():
             v[self.pointer] = transition[k]
         if self._agent is not None:
-            self._agent.add_transition(transition)
+            self._agent.add_transition(transition, replay=self._as_replay)
         self.pointer = (self.pointer + 1) % self.max_size
         self.size = max(self.pointer, self.size)
 
     def clear(self):
         self.size = self.pointer = 0
 
-    def attach(self, agent, capacity=None):
+    _as_replay = False
+
+    def attach(self, agent, capacity=None, replay=False):
+        """replay=False: this buffer IS the training dataset (main.py:111-115, create_from_initial_dataset): upload rows [0, size) into a
+        device ring of max_size rows.  replay=True: the separate, initially empty buffer of balanced sampling (main.py:106-109) -> the
+        engine's replay ring (agent.update_balanced draws half of each batch from it); rows already held are inserted one by one."""
         n = int(self.size)
-        agent.upload_dataset({k: np.ascontiguousarray(self[k][:n], dtype=np.float32) for k in KEYS[:5]}, capacity=self.max_size)
+        if replay:
+            agent.create_replay_buffer(self.max_size)
+            self._agent, self._as_replay = agent, True
+            for i in range(n):
+                agent.add_transition({k: self[k][i] for k in self}, replay=True)
+            return self
+        if np.asarray(self['observations']).ndim == 4:   # uint8 frames
+            agent.upload_dataset({k: self[k][:n] for k in KEYS}, frame_stack=self.frame_stack or 1, p_aug=self.p_aug or 0.0)
+            agent.reserve_dataset(self.max_size)
+        else:
+            agent.upload_dataset({k: np.ascontiguousarray(self[k][:n], dtype=np.float32) for k in KEYS[:5]}, capacity=self.max_size)
         self._agent = agent
         return self

@@ -205,6 +205,33 @@ int fql_dataset_upload_frames(fql_handle h, int64_t n, const uint8_t* frames, co
 int fql_update_from_frames(fql_handle h, const int64_t* idx, const int32_t* crop_froms, int batch_size, int64_t lo,
                            int64_t hi, const fql_noise* noise, float* info13, void* stream);
 
+/* ---- online fine-tuning hooks (main.py:217-272) ------------------------------------------------------------------------------
+ * ReplayBuffer.create_from_initial_dataset(dataset, size) (utils/datasets.py:457-473, main.py:111-115): grow the uploaded dataset
+ * (state or frames) to a ring of `capacity` >= current rows, new rows zero; size and pointer stay at the row count.  For frames
+ * the episode starts are NOT recomputed on insert, as in the reference (Dataset.__init__ computes initial_locs once): rows
+ * inserted later clamp their frame stack at the last episode start of the initial data. */
+int fql_dataset_reserve(fql_handle h, int64_t capacity);
+/* ReplayBuffer.add_transition (utils/datasets.py:483-491) for a frames dataset: one uint8 frame pair [img_h, img_w, img_c / frame_stack]
+ * + action, reward, mask into the ring.  Device or host pointers. */
+int fql_dataset_add_frames(fql_handle h, const uint8_t* frame, const uint8_t* next_frame, const float* action, float reward,
+                           float mask);
+/* ReplayBuffer.create(example_transition, size) (utils/datasets.py:441-455; main.py:106-109, --balanced_sampling): a second,
+ * initially empty ring of `capacity` rows in HBM beside the training dataset; state rows or uint8 frames as the agent has them
+ * (frames: after fql_dataset_upload_frames, whose frame_stack and p_aug it shares, main.py:117-120). */
+int fql_replay_create(fql_handle h, int64_t capacity);
+int fql_replay_add(fql_handle h, const float* observation, const float* action, float reward, float mask,
+                   const float* next_observation);
+int fql_replay_add_frames(fql_handle h, const uint8_t* frame, const uint8_t* next_frame, const float* action, float reward,
+                          float mask);
+int fql_replay_size(fql_handle h, int64_t* size, int64_t* pointer);
+/* main.py:255-259 + :216: batch = concat(train_dataset.sample(B // 2), replay_buffer.sample(B // 2)); agent.update(batch), without
+ * leaving the device.  idx_dataset / idx_replay: int64 [B / 2] each (device or host), or both NULL = uniform draws over the
+ * dataset rows / the replay ring's `size` rows from the engine RNG.  crop_froms (frames only): int32 [B, 2] or NULL = one
+ * augmentation coin per HALF (two sample() calls in the reference), offsets per row.  batch_size must be even and equal to the
+ * workspace batch; FQL_E_INVALID while the replay ring is empty. */
+int fql_update_balanced(fql_handle h, const int64_t* idx_dataset, const int64_t* idx_replay, const int32_t* crop_froms,
+                        int batch_size, const fql_noise* noise, float* info13, void* stream);
+
 /* Blocking read of the info of the last update (the reference reads lazily at log time, main.py:276). */
 int fql_read_info(fql_handle h, float* info13_host);
 /* Lazy infos, as the reference's `agent, info = agent.update(batch)` returns them (device scalars nobody waits for until they are
