@@ -70,6 +70,7 @@ SYMBOLS = {
     'fql_dataset_upload': (_I, [_VP, _I64, _I64, _VP, _VP, _VP, _VP, _VP]),
     'fql_dataset_add': (_I, [_VP, _VP, _VP, _F, _F, _VP]),
     'fql_dataset_size': (_I, [_VP, C.POINTER(_I64), C.POINTER(_I64)]),
+    'fql_noise_from_jax_keys': (_I, [_VP, _VP, _I, _I, C.POINTER(FqlNoise), _VP]),
     'fql_dataset_reserve': (_I, [_VP, _I64]),
     'fql_dataset_add_frames': (_I, [_VP, _VP, _VP, _VP, _F, _F]),
     'fql_replay_create': (_I, [_VP, _I64]),

@@ -126,7 +126,7 @@ class FQLAgent:
         self._sample_calls = 0
         # agents/fql.py:189-190: rng = PRNGKey(seed); rng, init_rng = split(rng, 2).  Only used when config['rng'] ==
         # 'jax' (noise drawn on the host with the reference's key derivation) or when a caller passes JAX keys.
-        self.rng = jax_prng.split(jax_prng.PRNGKey(seed), 2)[0]
+        self.rng = jax_prng.split(jax_prng.PRNGKey(seed), 2, partitionable=bool(self._jax_mode()))[0]
 
     # -- construction ---------------------------------------------------------------------
     @classmethod
@@ -236,13 +236,34 @@ class FQLAgent:
         every N steps (main.py:216,276) never synchronises in between.  want_info=False returns None (no snapshot at all)."""
         B, args = self._batch_args(batch)
         self._ensure_batch(B)
-        if noise is None and self.config.get('rng') == 'jax':
-            self.rng, noise = jax_prng.fql_update_noise(self.rng, B, self.config['action_dim'])
+        jax_mode = self._jax_mode()
+        if noise is None and jax_mode is not None and not self.config.get('rng_device', True):
+            self.rng, noise = jax_prng.fql_update_noise(self.rng, B, self.config['action_dim'], partitionable=jax_mode)
         nz, nargs = self._noise_args(noise, B)
         stream = self._stream(args + nargs)
+        if noise is None and jax_mode is not None:
+            # the reference's key derivation on the host (a dozen 2-word hashes), the five tensors on the device: nothing but 10 words
+            # of keys crosses PCIe (config['rng_device']=False: tensors drawn on the host by fql_amd/jax_prng.py instead)
+            self.rng, keys = jax_prng.fql_update_keys(self.rng, partitionable=jax_mode)
+            nz = self._device_noise(keys, jax_mode, B, stream)
         self._check(self._lib.fql_update(self._h, *[a.ptr for a in args], B, C.byref(nz) if nz else None, None, stream))
         self._keep = (args, nargs)
         return self, (self._lazy_info(stream) if want_info else None)
+
+    def _jax_mode(self):
+        """None: engine RNG; False / True: JAX key derivation with the original / partitionable threefry layout."""
+        r = self.config.get('rng')
+        if r == 'jax':
+            return False
+        if r == 'jax_partitionable':
+            return True
+        return None
+
+    def _device_noise(self, keys, partitionable, B, stream):
+        k = np.ascontiguousarray(np.stack([np.asarray(keys[n], dtype=np.uint32).reshape(2) for n in NOISE_KEYS]))
+        nz = _cabi.FqlNoise()
+        self._check(self._lib.fql_noise_from_jax_keys(self._h, k.ctypes.data, int(bool(partitionable)), B, C.byref(nz), stream))
+        return nz
 
     def _lazy_info(self, stream):
         t = C.c_uint64()
@@ -261,8 +282,9 @@ class FQLAgent:
             raise NotImplementedError('total_loss with traced grad_params is jax.grad plumbing; use update()')
         B, args = self._batch_args(batch)
         self._ensure_batch(B)
-        if noise is None and (rng is not None or self.config.get('rng') == 'jax'):
-            noise = jax_prng.fql_total_loss_noise(self.rng if rng is None else rng, B, self.config['action_dim'])
+        if noise is None and (rng is not None or self._jax_mode() is not None):
+            noise = jax_prng.fql_total_loss_noise(self.rng if rng is None else rng, B, self.config['action_dim'],
+                                                  partitionable=bool(self._jax_mode()))
         nz, nargs = self._noise_args(noise, B)
         loss = C.c_float()
         info = (C.c_float * 10)()
@@ -290,7 +312,7 @@ class FQLAgent:
         lead = tuple(observations.shape[:-3]) if vis else tuple(observations.shape[:-1])
         if not flow and noises is None and seed is not None and np.ndim(seed) == 1 and np.size(seed) == 2:
             # a JAX key (what main.py:225 / utils/evaluation.py:98-101 pass): draw exactly the noise the reference draws
-            noises = jax_prng.sample_actions_noise(np.asarray(seed), lead, ad)
+            noises = jax_prng.sample_actions_noise(np.asarray(seed), lead, ad, partitionable=bool(self._jax_mode()))
         if not vis and int(observations.shape[-1]) != od:
             raise ValueError(f'observations last dim must be {od}, got {tuple(observations.shape)}')
         n = int(np.prod(lead)) if lead else 1

@@ -32,5 +32,7 @@ def get_config():
         flow_steps=10,
         normalize_q_loss=False,
         encoder=None,
-        rng='engine',  # not a reference key: 'engine' = device Philox noise; 'jax' = host threefry, reference key derivation
+        rng='engine',  # not a reference key: 'engine' = device Philox noise; 'jax' / 'jax_partitionable' = the reference's key derivation with
+                       # JAX's original / partitionable threefry layout (keys on the host, tensors on the device: fql_noise_from_jax_keys)
+        rng_device=True,  # not a reference key: False draws the JAX-mode tensors on the host (fql_amd/jax_prng.py) and ships them H2D
     )

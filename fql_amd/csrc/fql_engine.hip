@@ -3172,6 +3172,24 @@ int fql_dataset_size(fql_handle h, int64_t* size, int64_t* pointer) {
     return FQL_OK;
 }
 // ---- online fine-tuning: ring capacity, uint8 ring insert, the replay ring of balanced sampling (helpers above extern "C")
+int fql_noise_from_jax_keys(fql_handle h, const uint32_t* keys10, int partitionable, int batch_size, fql_noise* out, void* stream) {
+    if (!h || !keys10 || !out) return FQL_E_INVALID;
+    FQL_TRY(h, {
+        if (batch_size != h->B) invalid("batch_size %d does not match the engine's workspace (%d); call fql_set_batch_size", batch_size, h->B);
+        hipStream_t s = pick(h, stream);
+        const int B = h->B, ad = h->cfg.act_dim;
+        JaxNoiseArgs a{};
+        for (int w = 0; w < 5; ++w) {
+            a.key[w][0] = keys10[2 * w]; a.key[w][1] = keys10[2 * w + 1];
+            a.out[w] = h->in_noise[w];
+            a.n[w] = w == 2 ? B : B * ad;
+        }
+        a.partitionable = partitionable ? 1 : 0;
+        hipLaunchKernelGGL(fql_jax_noise_kernel, dim3((B * ad + FQL_THREADS - 1) / FQL_THREADS, 5), dim3(FQL_THREADS), 0, s, a);
+        HIP_CHECK(hipGetLastError());
+        out->eps1 = h->in_noise[0]; out->x0 = h->in_noise[1]; out->t = h->in_noise[2]; out->z = h->in_noise[3]; out->eps2 = h->in_noise[4];
+    });
+}
 int fql_dataset_reserve(fql_handle h, int64_t capacity) {
     if (!h) return FQL_E_INVALID;
     FQL_TRY(h, {

@@ -205,6 +205,14 @@ int fql_dataset_upload_frames(fql_handle h, int64_t n, const uint8_t* frames, co
 int fql_update_from_frames(fql_handle h, const int64_t* idx, const int32_t* crop_froms, int batch_size, int64_t lo,
                            int64_t hi, const fql_noise* noise, float* info13, void* stream);
 
+/* JAX-compatible noise generated on the device (agents/fql.py:24,49-54,62-63,82,125,143-150): keys10 = the five uint32[2] keys the
+ * reference's split chain derives for (eps1, x0, t, z, eps2) of one update (the chain itself is a dozen 2-word hashes: host side,
+ * fql_amd/jax_prng.py fql_update_keys); partitionable = the jax_threefry_partitionable layout (0: original counter layout).
+ * The tensors are written on `stream` into engine-owned device buffers and *out is filled with pointers to them: pass it as the
+ * `noise` argument of the next update call on the same stream (valid until the next call of this function or the next update
+ * given host noise).  No host tensor crosses PCIe. */
+int fql_noise_from_jax_keys(fql_handle h, const uint32_t* keys10, int partitionable, int batch_size, fql_noise* out, void* stream);
+
 /* ---- online fine-tuning hooks (main.py:217-272) ------------------------------------------------------------------------------
  * ReplayBuffer.create_from_initial_dataset(dataset, size) (utils/datasets.py:457-473, main.py:111-115): grow the uploaded dataset
  * (state or frames) to a ring of `capacity` >= current rows, new rows zero; size and pointer stay at the row count.  For frames

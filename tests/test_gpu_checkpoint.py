@@ -82,3 +82,35 @@ def test_jax_key_paths_match_oracle_with_host_threefry_noise():
     got = agent.sample_actions(batch['observations'], seed=key)
     want = ref.sample_actions(batch['observations'], J.sample_actions_noise(key, (B,), ad))
     np.testing.assert_allclose(got, want, atol=1e-5)
+
+
+@pytest.mark.parametrize('mode', ['jax', 'jax_partitionable'])
+def test_jax_noise_generated_on_the_device_matches_the_host_restatement(mode):
+    """fql_noise_from_jax_keys: the five tensors of an update from the reference's five keys, both threefry layouts.  Bits are exact
+    (t, a plain mantissa fill, must be EQUAL); normals go through the single-precision erf_inv polynomial on the device and scipy's
+    float64 erfinv on the host: <= 6e-7 * (1 + |x|).  The update with device noise equals the update given the host tensors."""
+    import fql_amd
+    from fql_amd import jax_prng as J
+    from tests.test_gpu_hardening import _draws
+    part = mode == 'jax_partitionable'
+    od, ad, B = 11, 5, 48                                  # (batch sizes are multiples of 16: the odd-size padding of the original layout cannot occur)
+    cfg, ds, batch, _ = make_problem(od, ad, B, (64, 64, 64), seed=61)
+    cfg['rng'] = mode
+    a = fql_amd.FQLAgent.create(9, batch['observations'][:1], batch['actions'][:1], cfg)
+    cfg_h = fql_amd.get_config(); cfg_h.update(dict(cfg)); cfg_h['rng_device'] = False
+    b = fql_amd.FQLAgent.create(9, batch['observations'][:1], batch['actions'][:1], cfg_h)
+    np.testing.assert_array_equal(a.rng, J.split(J.PRNGKey(9), 2, partitionable=part)[0])
+    rng = a.rng
+    for _ in range(2):
+        rng, keys = J.fql_update_keys(rng, partitionable=part)
+        want = J.noise_from_keys(keys, B, ad, partitionable=part)
+        _, ia = a.update(batch)
+        got, _, _ = _draws(a, B, od, ad)
+        np.testing.assert_array_equal(got['t'], want['t'])
+        for k in ('eps1', 'z', 'eps2'):
+            assert np.abs(got[k] - want[k]).max() <= 6e-7 * (1 + np.abs(want[k]).max()), k
+        assert np.abs(got['x0'] - want['x0']).max() <= 2e-6          # recovered as a - (a - x0): one more rounding
+        _, ib = b.update(batch)
+        assert_info_close(ia, ib, rtol=2e-5, atol=2e-6)
+    np.testing.assert_array_equal(a.rng, rng)
+    np.testing.assert_array_equal(b.rng, rng)
