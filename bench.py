@@ -153,6 +153,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     force_dp = bool(os.environ.get('FQL_BENCH_FORCE_DP'))  # exercise the RCCL path on one GPU (torchrun --nproc-per-node 1)
+    # RCCL prints a version banner on STDOUT at communicator creation; the contract is ONE json line there, so file descriptor 1 points
+    # at stderr until the line is printed
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if world > 1 or force_dp:
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
@@ -175,7 +179,7 @@ def main():
         ds = make_synthetic_dataset(args.rows, od, ad, seed=0)
         agent = fql_amd.FQLAgent.create(seed, ds['observations'][:1], ds['actions'][:1], cfg)
         up_kw = {}
-    dp = DataParallelFQL(agent) if dist is not None else None
+    dp = DataParallelFQL(agent, overlap=os.environ.get('FQL_DP_OVERLAP', '1') != '0') if dist is not None else None
     if dp is not None:
         dp.upload_shard(ds, **up_kw)          # this rank's rows only
     else:
@@ -291,7 +295,10 @@ def main():
                 out['cpu_baseline']['loss_delta'] = {'total_loss_gpu': round(float(lg), 6), 'total_loss_oracle': round(float(lr), 6),
                                                      'abs_delta': float(abs(lg - lr)),
                                                      'max_abs_delta_info': float(max(abs(ig[k] - ir[k]) for k in ir))}
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -56,6 +56,7 @@ SYMBOLS = {
     'fql_update': (_I, [_VP] + _BATCH + [C.POINTER(FqlNoise), _VP, _VP]),
     'fql_update_begin': (_I, [_VP] + _BATCH + [C.POINTER(FqlNoise), _VP]),
     'fql_update_end': (_I, [_VP, _VP, _VP]),
+    'fql_update_end_split': (_I, [_VP, _VP, _VP, _VP]),
     'fql_update_begin_split': (_I, [_VP] + _BATCH + [C.POINTER(FqlNoise), _VP, _VP]),
     'fql_update_from_dataset_begin_split': (_I, [_VP, _VP, _I, _I64, _I64, C.POINTER(FqlNoise), _VP, _VP]),
     'fql_grad_buckets': (_I, [_VP, C.POINTER(_SZ), C.POINTER(_SZ)]),

@@ -467,6 +467,10 @@ class FQLAgent:
     def update_end(self, stream=None):
         self._check(self._lib.fql_update_end(self._h, None, stream))
 
+    def update_end_split(self, stream0, stream1):
+        """fql_update_end_split: Adam of gradient bucket 0 (critic, BC flow) on stream1, of bucket 1 (one-step actor) on stream0."""
+        self._check(self._lib.fql_update_end_split(self._h, None, stream0, stream1))
+
     def grad_buckets(self):
         """[(offset, length)] x 2 in floats inside grad_buffer(), or None if the engine has no split program."""
         off, ln = (C.c_size_t * 2)(), (C.c_size_t * 2)()

@@ -295,7 +295,8 @@ struct fql_engine {
     Program prog_split;
     hipGraphExec_t split_exec[4] = {nullptr, nullptr, nullptr, nullptr};  // A0 (prep), B (lane 1), A1, A2
     hipGraph_t split_graph[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
+    bool split_begun = false;   // the pending update was begun by launch_split (ev_c marks the end of lane 0's pre-join part)
     bool began = false;
 
     // dataset
@@ -2015,8 +2016,11 @@ struct fql_engine {
         HIP_CHECK(hipGraphLaunch(split_exec[1], s1));
         HIP_CHECK(hipEventRecord(ev_b, s1));
         HIP_CHECK(hipGraphLaunch(split_exec[2], s0));
+        if (!ev_c) HIP_CHECK(hipEventCreateWithFlags(&ev_c, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(ev_c, s0));          // the Euler chain (the last reader of the BC flow's weights on lane 0) is behind this
         HIP_CHECK(hipStreamWaitEvent(s0, ev_b, 0));
         HIP_CHECK(hipGraphLaunch(split_exec[3], s0));
+        split_begun = true;
     }
 
     void free_program(Program& pr) {
@@ -2264,34 +2268,9 @@ struct fql_engine {
         }
     }
 
-    void build_opt_program(Program& pr) {
-        emit_lane = 0;
+    // Adam (+ Polyak for the critic) of one module (0 BC flow, 1 one-step actor, 2 critic) as its own launch on `lane`
+    void adam_for(Program& pr, int m, std::initializer_list<int> net_ids, int lane) {
         DevState* st = d_state;
-        const void* INFO = &st->info[0];
-        Op a{};
-        a.type = OP_ADAM;
-        a.reads = {st, G};
-        a.writes = {P, Mu, Nu, INFO};
-        push(pr, a);
-        if (use_chain) {   // the Adam op above names the whole arena as P: order the refresh behind it explicitly
-            const size_t i0 = pr.ops.size();
-            emit_wfrag(pr);
-            pr.ops[i0].reads.push_back(P);
-        }
-        Op f{};
-        f.type = OP_FINALIZE;
-        f.fin_mode = 1;
-        f.reads = {INFO};
-        f.writes = {INFO, st};
-        push(pr, f);
-    }
-
-    // fwd + bwd + optimizer in one graph (single-GPU calls): Adam of a module is issued on the lane that produced its
-    // gradients as soon as they exist, so 3/4 of the optimizer pass overlaps the tail of the critical lane
-    void build_full_program(Program& pr) {
-        build_step_program(pr, true);
-        DevState* st = d_state;
-        auto adam_for = [&](int m, std::initializer_list<int> net_ids, int lane) {
             Op a{};
             a.type = OP_ADAM;
             a.adam_c0 = mod_chunk0[m]; a.adam_n = mod_chunkn[m];
@@ -2319,11 +2298,62 @@ struct fql_engine {
                 }
             emit_lane = lane;
             push(pr, a);
-        };
-        adam_for(2, {NET_C0, NET_C1}, fill_lane_full);
-        adam_for(0, {NET_BC}, fill_lane_full);
+        }
+
+    // The optimizer half of the begin / end pair (data-parallel step: gradients are all-reduced between the halves): per-module Adam
+    // as in the fused program - critic and BC flow (gradient bucket 0) + the chain's weight-copy refresh on lane 1, the one-step
+    // actor (bucket 1) and the bookkeeping on lane 0.  fql_update_end captures it as one two-lane graph; fql_update_end_split issues
+    // lane 1 on the stream that carried bucket 0's all-reduce, so those Adam launches overlap lane 0's tail and bucket 1's reduce.
+    void build_opt_program(Program& pr) {
+        DevState* st = d_state;
+        adam_for(pr, 2, {NET_C0, NET_C1}, 1);
+        adam_for(pr, 0, {NET_BC}, 1);
+        if (use_chain) { emit_lane = 1; emit_wfrag(pr); }
+        adam_for(pr, 1, {NET_OS}, 0);
+        Op f{};
+        f.type = OP_FINALIZE;
+        f.fin_mode = 1;
+        f.reads = {d_partials + mod_chunk0[0] * 4, d_partials + mod_chunk0[1] * 4, d_partials + mod_chunk0[2] * 4, &st->info[0],
+                   &st->info[4], &st->info[5], &st->info[7], &st->info[9]};
+        f.writes = {&st->info[10], st};
+        emit_lane = 0;
+        push(pr, f);
+    }
+    // the optimizer program as plain launches on two caller streams (no capture: five launches)
+    void run_opt_split(hipStream_t s0, hipStream_t s1) {
+        Program& pr = prog_opt;
+        // lane 1 rewrites the critic's and the BC flow's parameters (and the chain's weight copies): it must not pass lane 0's last
+        // reader of them, the Euler chain.  After a split begin that point is ev_c; otherwise everything enqueued on s0 so far.
+        if (!ev_c) HIP_CHECK(hipEventCreateWithFlags(&ev_c, hipEventDisableTiming));
+        if (!split_begun) HIP_CHECK(hipEventRecord(ev_c, s0));
+        HIP_CHECK(hipStreamWaitEvent(s1, ev_c, 0));
+        split_begun = false;
+        for (Launch& L : pr.launches) {
+            hipStream_t s = L.lane == 0 ? s0 : s1;
+            for (int w : L.waits) if (pr.launches[w].ev) HIP_CHECK(hipStreamWaitEvent(s, pr.launches[w].ev, 0));
+            issue(L, s, -1);
+            if (L.record_after) {
+                if (!L.ev) HIP_CHECK(hipEventCreateWithFlags(&L.ev, hipEventDisableTiming));
+                HIP_CHECK(hipEventRecord(L.ev, s));
+            }
+        }
+        if (pr.lane_used[1]) {   // s0 ends behind everything of the update
+            if (!pr.ev_join[1]) HIP_CHECK(hipEventCreateWithFlags(&pr.ev_join[1], hipEventDisableTiming));
+            HIP_CHECK(hipEventRecord(pr.ev_join[1], s1));
+            HIP_CHECK(hipStreamWaitEvent(s0, pr.ev_join[1], 0));
+        }
+        HIP_CHECK(hipGetLastError());
+    }
+
+    // fwd + bwd + optimizer in one graph (single-GPU calls): Adam of a module is issued on the lane that produced its
+    // gradients as soon as they exist, so 3/4 of the optimizer pass overlaps the tail of the critical lane
+    void build_full_program(Program& pr) {
+        build_step_program(pr, true);
+        DevState* st = d_state;
+        adam_for(pr, 2, {NET_C0, NET_C1}, fill_lane_full);
+        adam_for(pr, 0, {NET_BC}, fill_lane_full);
         emit_wfrag(pr);   // lane 1, behind the BC flow's Adam: the next update's chain reads the copies
-        adam_for(1, {NET_OS}, 0);
+        adam_for(pr, 1, {NET_OS}, 0);
         Op f{};
         f.type = OP_FINALIZE;
         f.fin_mode = 1;
@@ -3050,6 +3080,7 @@ int fql_update_begin(fql_handle h, const float* obs, const float* act, const flo
         h->source_from_batch(obs, act, rew, mask, nobs, batch_size, noise, 1, s);
         run_program(h, h->prog_fwdbwd, s);
         h->began = true;
+        h->split_begun = false;
     });
 }
 int fql_update_end(fql_handle h, float* info13, void* stream) {
@@ -3300,6 +3331,7 @@ int fql_update_from_dataset_begin(fql_handle h, const int64_t* idx, int batch_si
         h->source_from_dataset(idx, batch_size, lo, hi, noise, s);
         run_program(h, h->prog_fwdbwd, s);
         h->began = true;
+        h->split_begun = false;
     });
 }
 int fql_update_from_dataset_begin_split(fql_handle h, const int64_t* idx, int batch_size, int64_t lo, int64_t hi,
@@ -3320,6 +3352,16 @@ int fql_update_begin_split(fql_handle h, const float* obs, const float* act, con
         h->source_from_batch(obs, act, rew, mask, nobs, batch_size, noise, 1, (hipStream_t)stream0);
         h->launch_split((hipStream_t)stream0, (hipStream_t)stream1);
         h->began = true;
+    });
+}
+int fql_update_end_split(fql_handle h, float* info13, void* stream0, void* stream1) {
+    if (!h) return FQL_E_INVALID;
+    if (!h->began) { h->err = "fql_update_end_split without fql_update_begin"; return FQL_E_STATE; }
+    if (!stream0 || !stream1 || stream0 == stream1) { h->err = "fql_update_end_split needs two distinct streams"; return FQL_E_STATE; }
+    FQL_TRY(h, {
+        h->run_opt_split((hipStream_t)stream0, (hipStream_t)stream1);
+        h->began = false;
+        h->finish_info(info13, FQL_NUM_INFO, (hipStream_t)stream0);
     });
 }
 int fql_grad_buckets(fql_handle h, size_t offsets[2], size_t lengths[2]) {

@@ -181,8 +181,9 @@ class DataParallelFQL:
                 self._reduce(self.g0)
             with torch.cuda.stream(main):
                 self._reduce(self.g1)
-        main.wait_stream(side)
-        self.agent.update_end(stream=main.cuda_stream)
+        # Adam of the critic / BC flow right behind bucket 0 on `side` (beside lane 0's tail and bucket 1's reduce), the one-step actor's
+        # and the bookkeeping on `main`, which ends behind both
+        self.agent.update_end_split(main.cuda_stream, side.cuda_stream)
         outer.wait_stream(main)
 
     def update(self, batch, noise=None):

@@ -149,6 +149,11 @@ int fql_update_begin_split(fql_handle h, const float* observations, const float*
                            const fql_noise* noise, void* stream0, void* stream1);
 int fql_update_from_dataset_begin_split(fql_handle h, const int64_t* idx, int batch_size, int64_t lo, int64_t hi,
                                         const fql_noise* noise, void* stream0, void* stream1);
+/* The optimizer half on the two streams of the split begin: Adam (+ Polyak) of the critic and the BC flow - gradient bucket 0 - and the
+ * refresh of the Euler chain's weight copies on stream1 (behind bucket 0's all-reduce, which the caller enqueued there), Adam of the
+ * one-step actor - bucket 1 - and the step bookkeeping on stream0 (behind bucket 1's all-reduce); stream0 ends behind both.  Same
+ * result as fql_update_end. */
+int fql_update_end_split(fql_handle h, float* info13, void* stream0, void* stream1);
 /* offsets / lengths (in floats) of the two gradient buckets inside the buffer fql_grad_buffer returns */
 int fql_grad_buckets(fql_handle h, size_t offsets[2], size_t lengths[2]);
 int fql_grad_buffer(fql_handle h, void** device_ptr, size_t* num_floats);
