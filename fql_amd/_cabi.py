@@ -101,7 +101,10 @@ def load():
             f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
             '(hipcc --offload-arch=gfx950).  fql_amd has no CPU fallback.')
     lib = C.CDLL(LIB_PATH)
+    lax = 'FQL_AMD_LIB' in os.environ    # experiments load older builds through the env override: bind what they export
     for name, (res, args) in SYMBOLS.items():
+        if lax and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args

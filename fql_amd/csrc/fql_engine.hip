@@ -13,6 +13,7 @@
 #include "fql_kernels.h"
 #include "fql_conv.h"
 #include "fql_chain.h"
+#include "fql_aux.h"
 
 #include <algorithm>
 #include <atomic>
