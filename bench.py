@@ -13,8 +13,9 @@ N > 1 (launched by torch.distributed.run): one process per GPU, replay sharded P
 Prints ONE JSON line on rank 0.  Besides the contract fields:
   roofline      per-kernel: the kernel family with the largest device time per update, its algorithmic FLOPs per launch
                 (GEMM-shaped tasks, SURVEY.md 8d accounting) over its average launch duration, measured HERE with HIP events on
-                the engine's stream (fql_profile_update: the update's launches issued eagerly, one stream, an event around each -
-                the same serialised view rocprofv3 --kernel-trace gives; profiles/r02_kernel_stats.csv must agree);
+                the engine's stream (fql_profile_update: the update's launches issued in program order on one stream, a start / stop
+                event pair attached to each dispatch - the dispatch duration rocprofv3 --kernel-trace reports, same serialised view;
+                profiles/r02_kernel_stats.csv must agree);
                 `traffic` / `mfma_util` come from the committed rocprofv3 --pmc summary (profiles/r02_pmc_summary.json), collected
                 in separate passes as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 for 16-byte-per-lane reads on gfx950)
   whole_update  the same accounting over the whole update on the fenced wall clock
@@ -106,8 +107,9 @@ def profile_kernels(agent, B, reps):
         if r < 2:
             continue   # warm-up passes
         nulls.append(null_us.value)
-        # event-to-event interval = launch gap + kernel; the gap is calibrated on an empty kernel (which itself shows ~1.4 us in a trace)
-        gap = max(0.0, null_us.value - 1.4)
+        # the start / stop events ride on each dispatch (hipExtLaunchKernelGGL): their elapsed time is the dispatch's own duration, the
+        # quantity `rocprofv3 --kernel-trace --stats` averages - nothing to calibrate
+        gap = 0.0
         for i in range(n):
             d = fam.setdefault(OP_NAMES[typ[i]], {'launches': 0, 'us': 0.0, 'macs': 0.0, 'min_us': 1e9, 'max_us': 0.0, 'raw': 0.0})
             t = max(0.5, us[i] - gap)
@@ -247,10 +249,9 @@ def main():
                         'frac': round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': dom,
                         'flop_per_launch': round(d['flop_per_launch']), 'avg_launch_us': round(d['avg_us'], 3),
                         'launches_per_update': round(d['launches_per_update'], 2),
-                        'event_interval_us': round(d['event_interval_us'], 3), 'null_interval_us': round(d['null_interval_us'], 3),
-                        'measured': 'HIP events on the engine stream around every launch of 20 updates issued eagerly in program order '
-                                    '(fql_profile_update; serialised like rocprofv3 --kernel-trace); avg_launch_us = event interval minus the '
-                                    'launch gap calibrated on an empty kernel (null interval - 1.4 us)'}
+                        'measured': 'start / stop HIP events attached to every dispatch (hipExtLaunchKernelGGL) of 20 updates issued in program '
+                                    'order on the engine stream (fql_profile_update; serialised like rocprofv3 --kernel-trace): avg_launch_us = mean '
+                                    'elapsed time of the pair = the dispatch duration a kernel trace reports'}
                 pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_summary.json')
                 if os.path.exists(pmc) and not visual:
                     try:

@@ -14,6 +14,7 @@
 #include "fql_conv.h"
 #include "fql_chain.h"
 #include "fql_aux.h"
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <atomic>
@@ -1649,117 +1650,126 @@ struct fql_engine {
     }
 
     // one launch of a program on stream s (tl: timeline id of the diagnostics build, -1 = none); reads engine state only
+    // Per-launch profiling (fql_profile_update): when set, the next launch carries these two events ON ITS DISPATCH
+    // (hipExtLaunchKernelGGL): their elapsed time is the dispatch's own begin-to-end time, the quantity a rocprofv3 kernel trace reports.
+    hipEvent_t prof_a = nullptr, prof_b = nullptr;
+#define FQL_LAUNCH(k, g, b, l, st, ...)                                                          \
+    do {                                                                                          \
+        if (prof_a) hipExtLaunchKernelGGL(k, g, b, (std::uint32_t)(l), st, prof_a, prof_b, 0u, __VA_ARGS__); \
+        else hipLaunchKernelGGL(k, g, b, l, st, __VA_ARGS__);                                     \
+    } while (0)
     void issue(const Launch& L, hipStream_t s, int tl) {
         static const int side_prio = getenv("FQL_SIDE_PRIO") ? atoi(getenv("FQL_SIDE_PRIO")) : 0;
         switch (L.type) {
             case OP_GEMM:
-                if (L.euler && L.kbig) hipLaunchKernelGGL((fql_gemm16_euler_kernel<true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
-                else if (L.euler) hipLaunchKernelGGL((fql_gemm16_euler_kernel<false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
-                else if (L.tmt2 && L.kbig) hipLaunchKernelGGL((fql_gemm16_kernel<true, true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
-                else if (L.tmt2) hipLaunchKernelGGL((fql_gemm16_kernel<true, false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
-                else if (L.kbig) hipLaunchKernelGGL((fql_gemm16_kernel<false, true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
-                else hipLaunchKernelGGL((fql_gemm16_kernel<false, false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
+                if (L.euler && L.kbig) FQL_LAUNCH((fql_gemm16_euler_kernel<true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
+                else if (L.euler) FQL_LAUNCH((fql_gemm16_euler_kernel<false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
+                else if (L.tmt2 && L.kbig) FQL_LAUNCH((fql_gemm16_kernel<true, true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
+                else if (L.tmt2) FQL_LAUNCH((fql_gemm16_kernel<true, false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
+                else if (L.kbig) FQL_LAUNCH((fql_gemm16_kernel<false, true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
+                else FQL_LAUNCH((fql_gemm16_kernel<false, false>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
                 break;
             case OP_GEMM64:
                 if (L.side && L.tmt2)
-                    hipLaunchKernelGGL(fql_side_big_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks,
+                    FQL_LAUNCH(fql_side_big_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks,
                                        (const WgradTask*)L.table_w, L.n_w, (const LnBwdTask*)L.table_l, L.n_l, L.tile_w, L.tile_l,
                                        (const MiscTask*)L.table_m, L.tile_m, 0, tl);
                 else if (L.side)
-                    hipLaunchKernelGGL(fql_side_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks,
+                    FQL_LAUNCH(fql_side_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks,
                                        (const WgradTask*)L.table_w, L.n_w, (const LnBwdTask*)L.table_l, L.n_l, L.tile_w, L.tile_l,
                                        (const MiscTask*)L.table_m, L.tile_m, side_prio, tl);
                 else
-                    hipLaunchKernelGGL(fql_gemm64_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
+                    FQL_LAUNCH(fql_gemm64_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks);
                 break;
             case OP_WGRAD:
-                hipLaunchKernelGGL(fql_wgrad_kernel, dim3(L.grid), dim3(FQL_THREADS), 0, s, (const WgradTask*)L.table, L.ntasks);
+                FQL_LAUNCH(fql_wgrad_kernel, dim3(L.grid), dim3(FQL_THREADS), 0, s, (const WgradTask*)L.table, L.ntasks);
                 break;
             case OP_LNBWD:
-                hipLaunchKernelGGL(fql_lnbwd_kernel, dim3(L.grid), dim3(FQL_THREADS), 0, s, (const LnBwdTask*)L.table, L.ntasks);
+                FQL_LAUNCH(fql_lnbwd_kernel, dim3(L.grid), dim3(FQL_THREADS), 0, s, (const LnBwdTask*)L.table, L.ntasks);
                 break;
             case OP_PREP:
-                { PrepArgs pa = L.op.prep; pa.tl = tl; hipLaunchKernelGGL(fql_prep_kernel, dim3((pa.B + 3) / 4), dim3(FQL_THREADS), 0, s, pa); }
+                { PrepArgs pa = L.op.prep; pa.tl = tl; FQL_LAUNCH(fql_prep_kernel, dim3((pa.B + 3) / 4), dim3(FQL_THREADS), 0, s, pa); }
                 break;
             case OP_POSTOS:
-                hipLaunchKernelGGL(fql_post_onestep_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.postos);
+                FQL_LAUNCH(fql_post_onestep_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.postos);
                 break;
             case OP_PEC: {
                 const PecArgs& a = L.op.pec;
                 const int T = cfg.actor_hidden[0] / 32;
                 const size_t lds = ((size_t)16 * (cfg.actor_hidden[0] + 4) + 1024 + 576 + 512 * (size_t)a.ntile) * sizeof(float);
-                if (cfg.actor_hidden[0] == 512) hipLaunchKernelGGL((fql_euler_persistent_kernel<512>), dim3(a.nteams * T), dim3(FQL_THREADS), lds, s, a);
-                else hipLaunchKernelGGL((fql_euler_persistent_kernel<256>), dim3(a.nteams * T), dim3(FQL_THREADS), lds, s, a);
+                if (cfg.actor_hidden[0] == 512) FQL_LAUNCH((fql_euler_persistent_kernel<512>), dim3(a.nteams * T), dim3(FQL_THREADS), lds, s, a);
+                else FQL_LAUNCH((fql_euler_persistent_kernel<256>), dim3(a.nteams * T), dim3(FQL_THREADS), lds, s, a);
                 break;
             }
             case OP_EULER_FIN:
-                hipLaunchKernelGGL(fql_euler_finish_kernel, dim3((L.op.ef.M * L.op.ef.ad + FQL_THREADS - 1) / FQL_THREADS), dim3(FQL_THREADS), 0, s, L.op.ef);
+                FQL_LAUNCH(fql_euler_finish_kernel, dim3((L.op.ef.M * L.op.ef.ad + FQL_THREADS - 1) / FQL_THREADS), dim3(FQL_THREADS), 0, s, L.op.ef);
                 break;
             case OP_LOSS_CRITIC:
-                hipLaunchKernelGGL(fql_loss_critic_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.lc);
+                FQL_LAUNCH(fql_loss_critic_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.lc);
                 break;
             case OP_LOSS_Q:
-                hipLaunchKernelGGL(fql_loss_q_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.lq);
+                FQL_LAUNCH(fql_loss_q_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.lq);
                 break;
             case OP_LOSS_BC:
-                hipLaunchKernelGGL(fql_loss_bc_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.lb);
+                FQL_LAUNCH(fql_loss_bc_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.lb);
                 break;
             case OP_LOSS_ACTOR:
-                hipLaunchKernelGGL(fql_loss_actor_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.la);
+                FQL_LAUNCH(fql_loss_actor_kernel, dim3(1), dim3(FQL_THREADS), 0, s, L.op.la);
                 break;
             case OP_CONV_WPREP:
-                hipLaunchKernelGGL(fql_conv_wprep_kernel, dim3(4, L.op.wprep_n), dim3(FQL_THREADS), 0, s, L.op.wprep_tasks);
+                FQL_LAUNCH(fql_conv_wprep_kernel, dim3(4, L.op.wprep_n), dim3(FQL_THREADS), 0, s, L.op.wprep_tasks);
                 break;
             case OP_CONV:
-                hipLaunchKernelGGL(fql_conv3x3_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
+                FQL_LAUNCH(fql_conv3x3_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
                 break;
             case OP_CONV_U8:
-                hipLaunchKernelGGL(fql_conv3x3_u8_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
+                FQL_LAUNCH(fql_conv3x3_u8_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
                 break;
             case OP_POOL: {
                 const PoolArgs& a = L.op.pool;
                 const size_t tot = (size_t)a.N * (a.H / 2) * (a.W / 2) * (a.C / 4);
-                hipLaunchKernelGGL(fql_maxpool_kernel, dim3((unsigned)((tot + FQL_THREADS - 1) / FQL_THREADS)), dim3(FQL_THREADS), 0, s, a);
+                FQL_LAUNCH(fql_maxpool_kernel, dim3((unsigned)((tot + FQL_THREADS - 1) / FQL_THREADS)), dim3(FQL_THREADS), 0, s, a);
                 break;
             }
             case OP_POOL_BWD: {
                 const PoolBwdArgs& a = L.op.poolb;
                 const size_t tot = (size_t)a.N * a.H * a.W * (a.C / 4);
-                hipLaunchKernelGGL(fql_maxpool_bwd_kernel, dim3((unsigned)((tot + FQL_THREADS - 1) / FQL_THREADS)), dim3(FQL_THREADS), 0, s, a);
+                FQL_LAUNCH(fql_maxpool_bwd_kernel, dim3((unsigned)((tot + FQL_THREADS - 1) / FQL_THREADS)), dim3(FQL_THREADS), 0, s, a);
                 break;
             }
             case OP_CONV_WGRAD:
-                hipLaunchKernelGGL(fql_conv_wgrad_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvWgradArgs*)L.table, L.ntasks);
+                FQL_LAUNCH(fql_conv_wgrad_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvWgradArgs*)L.table, L.ntasks);
                 break;
             case OP_CONV_WRED:
-                hipLaunchKernelGGL(fql_conv_wgrad_reduce_kernel, dim3(L.grid), dim3(FQL_THREADS), 0, s, (const ConvWredArgs*)L.table, L.ntasks);
+                FQL_LAUNCH(fql_conv_wgrad_reduce_kernel, dim3(L.grid), dim3(FQL_THREADS), 0, s, (const ConvWredArgs*)L.table, L.ntasks);
                 break;
             case OP_ENC_DZ: {
                 const EncDzArgs& a = L.op.edz;
-                hipLaunchKernelGGL(fql_enc_dz_kernel, dim3((a.M * a.n + FQL_THREADS - 1) / FQL_THREADS), dim3(FQL_THREADS), 0, s, a);
+                FQL_LAUNCH(fql_enc_dz_kernel, dim3((a.M * a.n + FQL_THREADS - 1) / FQL_THREADS), dim3(FQL_THREADS), 0, s, a);
                 break;
             }
             case OP_CHAIN: {
                 ChainArgs ca = L.op.chain; ca.tl = tl;
-                if (cfg.actor_hidden[0] == 512) hipLaunchKernelGGL((fql_chain_kernel<512>), dim3((L.op.chain.M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, ca);
-                else hipLaunchKernelGGL((fql_chain_kernel<256>), dim3((L.op.chain.M / 16) * 8), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(256), s, ca);
+                if (cfg.actor_hidden[0] == 512) FQL_LAUNCH((fql_chain_kernel<512>), dim3((L.op.chain.M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, ca);
+                else FQL_LAUNCH((fql_chain_kernel<256>), dim3((L.op.chain.M / 16) * 8), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(256), s, ca);
                 break;
             }
             case OP_WFRAG:
-                hipLaunchKernelGGL(fql_wfrag_kernel, dim3(wfrag_grid), dim3(FQL_THREADS), 0, s, (const WfragTask*)d_wfrag, wfrag_n, tl);
+                FQL_LAUNCH(fql_wfrag_kernel, dim3(wfrag_grid), dim3(FQL_THREADS), 0, s, (const WfragTask*)d_wfrag, wfrag_n, tl);
                 break;
             case OP_ADAM: {
                 AdamArgs a{P, G, Mu, Nu, P + n_train, d_chunks, d_state, d_partials, L.op.adam_c0, (int)critic_size, cfg.lr, cfg.tau, tl};
-                hipLaunchKernelGGL(fql_adam_kernel, dim3(L.op.adam_n < 0 ? n_chunks : L.op.adam_n), dim3(FQL_THREADS), 0, s, a);
+                FQL_LAUNCH(fql_adam_kernel, dim3(L.op.adam_n < 0 ? n_chunks : L.op.adam_n), dim3(FQL_THREADS), 0, s, a);
                 break;
             }
             case OP_FINALIZE:
-                hipLaunchKernelGGL(fql_finalize_kernel, dim3(1), dim3(FQL_THREADS), 0, s,
+                FQL_LAUNCH(fql_finalize_kernel, dim3(1), dim3(FQL_THREADS), 0, s,
                                    FinalizeArgs{d_state, d_chunks, d_partials, d_leaf_range, n_chunks, n_train_leaves, L.op.fin_mode, tl});
                 break;
         }
     }
 
+#undef FQL_LAUNCH
     // ---- threaded eager executor ---------------------------------------------------------------------------------------------
     // The lanes of a program issued as plain launches, each lane's stream fed by a host thread of its own (lane 0 by the caller).
     // Cross-lane dependencies: the producer records its event and then publishes the run's sequence number for that launch; the
@@ -3450,48 +3460,30 @@ extern "C" int fql_profile_update(fql_handle h, int batch_size, int cap, int* ty
     if (!h->prog_full.exec) { h->err = "no single-graph update program"; return FQL_E_STATE; }
     try {
         hipStream_t s = h->stream;
-        if (null_us) {
-            hipEvent_t a[33];
-            for (auto& e : a) HIP_CHECK(hipEventCreate(&e));
-            HIP_CHECK(hipEventRecord(a[0], s));
-            for (int i = 0; i < 32; ++i) {
-                hipLaunchKernelGGL(fql_extract_kernel, dim3(1), dim3(64), 0, s, (const float*)nullptr, (float*)nullptr, 0, 1, 1);
-                HIP_CHECK(hipEventRecord(a[i + 1], s));
-            }
-            HIP_CHECK(hipStreamSynchronize(s));
-            std::vector<float> v(32);
-            for (int i = 0; i < 32; ++i) { HIP_CHECK(hipEventElapsedTime(&v[i], a[i], a[i + 1])); v[i] *= 1e3f; }
-            std::sort(v.begin(), v.end());
-            *null_us = v[16];
-            for (auto& e : a) hipEventDestroy(e);
-        }
+        if (null_us) *null_us = 0.f;   // (no calibration needed: the events ride on the dispatches)
         h->source_from_dataset(nullptr, batch_size, 0, 0, nullptr, s);
         Program& pr = h->prog_full;
         const int n = (int)pr.launches.size();
-        std::vector<hipEvent_t> ev(n + 1);
+        std::vector<hipEvent_t> ev(2 * n);
         for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
-        Program one;   // one launch at a time through the ordinary launch switch
-        HIP_CHECK(hipEventRecord(ev[0], s));
-        for (int i = 0; i < n; ++i) {
-            one.launches.clear();
-            Launch L = pr.launches[i];
-            L.waits.clear(); L.record_after = false; L.ev = nullptr;
-            one.launches.push_back(L);
-            h->run_launches(one, s, false);
-            HIP_CHECK(hipEventRecord(ev[i + 1], s));
+        for (int i = 0; i < n; ++i) {   // the update's launches in program order on one stream, each dispatch carrying its own event pair
+            h->prof_a = ev[2 * i]; h->prof_b = ev[2 * i + 1];
+            h->issue(pr.launches[i], s, -1);
         }
+        h->prof_a = h->prof_b = nullptr;
+        HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(s));
         for (int i = 0; i < n && i < cap; ++i) {
             const Launch& L = pr.launches[i];
             float ms = 0.f;
-            HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            HIP_CHECK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
             type[i] = (int)L.type; if (lane) lane[i] = L.lane; if (grid) grid[i] = L.grid; us[i] = ms * 1e3f;
             if (macs) macs[i] = L.macs;
         }
         for (auto& e : ev) hipEventDestroy(e);
         return std::min(n, cap);
-    } catch (const Invalid& e) { h->err = e.msg; return FQL_E_INVALID; }
-    catch (const HipError& e) { h->err = e.msg; return FQL_E_HIP; }
+    } catch (const Invalid& e) { h->prof_a = h->prof_b = nullptr; h->err = e.msg; return FQL_E_INVALID; }
+    catch (const HipError& e) { h->prof_a = h->prof_b = nullptr; h->err = e.msg; return FQL_E_HIP; }
 }
 
 // Diagnostic only (not in include/fql_amd.h): copy a workspace buffer of the last update to the host, so tests can look at what the
