@@ -37,8 +37,11 @@ acc = None
 for r in range(reps):
     for _ in range(20):
         agent.update_from_dataset(B)
-    assert f(agent._h, 1, cap, lane, typ, grid, t0, t1, t2) == 0
-    agent.update_from_dataset(B)
+    assert f(agent._h, 1, cap, lane, typ, grid, t0, t1, t2) == 0      # (synchronises: the device is idle here)
+    # FQL_TL_STEADY=K: K updates back to back, the stamps that remain are the LAST one's (every launch overwrites its slots) - an update in
+    # steady state, its launches enqueued while the previous update was still running.  Default: ONE update launched on an idle device.
+    for _ in range(int(os.environ.get('FQL_TL_STEADY', '1'))):
+        agent.update_from_dataset(B)
     n = f(agent._h, 0, cap, lane, typ, grid, t0, t1, t2)
     assert n > 0, n
     cur = np.array([[t0[i], t1[i], t2[i]] for i in range(n)])

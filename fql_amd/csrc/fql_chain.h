@@ -25,6 +25,9 @@
 #include "fql_kernels.h"
 
 #define FQL_CHAIN_THREADS 512
+#ifndef FQL_CHAIN_WAVES
+#define FQL_CHAIN_WAVES 4   // min waves per SIMD the register allocation must allow (4: <= 128 VGPRs, the kernel needs 102)
+#endif
 
 struct ChainArgs {
     const float* A;       // B, C: input activations [M, H] row-major.  A: C0 in C-fragment-major layout [M/4][H][4]
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_wfrag_kernel(const WfragTask*
 }
 
 template <int H>
-__global__ __launch_bounds__(FQL_CHAIN_THREADS) void fql_chain_kernel(const ChainArgs P) {
+__global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_kernel(const ChainArgs P) {
     static_assert(H % 128 == 0 && H <= 1024, "hidden width must be a multiple of 128");
     constexpr int S = H + 4;          // LDS row stride of the A tile (floats)
     constexpr int GQ = H / 64;        // k-groups (of 16) per K-quarter

@@ -1679,6 +1679,7 @@ struct AdamArgs {
     int critic_size;
     float lr, tau;
     int tl;
+    const unsigned* err;   // persistent Euler chain only: its time-out word; set => the update's targets are invalid, leave the parameters alone
 };
 __device__ __forceinline__ int f2ord(float f) {
     const int i = __float_as_int(f);
@@ -1689,6 +1690,7 @@ __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i
 __global__ __launch_bounds__(FQL_THREADS) void fql_adam_kernel(AdamArgs A) {
     __shared__ float sh[4];
     tl_enter(A.tl);
+    if (A.err && __hip_atomic_load(A.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // (null unless FQL_PEC=1)
     const int cidx = (int)blockIdx.x + A.chunk0;
     const AdamChunk ch = A.chunks[cidx];  // <= 4096 elements, offset and length multiples of 4
     // optax bias correction with count = adam_count + 1 (the counters advance in the finalize kernel afterwards)
