@@ -282,6 +282,7 @@ struct fql_engine {
     int wfrag_n = 0, wfrag_grid = 0;
     std::vector<void*> chain_allocs;
     bool split_build = false;   // building the data-parallel program: lane 1 must not depend on lane 0's backward
+    bool wide_tiles = false;    // three-lane programs: 32 x 64 side tiles everywhere (the other lanes fill the CUs a launch leaves idle; +1 %)
     bool split_ok = false;
     int vp_tiles = 0;
     int pec_teams = 0;               // teams of the persistent chain (H/32 workgroups each, one workgroup per CU)
@@ -1382,7 +1383,7 @@ struct fql_engine {
                         for (const Op* o : sell) other += 0.05 * o->ln.M;
                         const int ncu = std::max(1, num_cus);
                         const double m64 = 2.0 * ((t64 + ncu - 1) / ncu) + other / ncu, m32 = 1.0 * ((2 * t64 + ncu - 1) / ncu) + other / ncu;
-                        if (t64 > 0 && m32 < m64) nj = 1;
+                        if (t64 > 0 && m32 < m64 && !wide_tiles) nj = 1;
                         if (nj_env == 1 || nj_env == 2) nj = nj_env;
                     }
                     for (const Op* o : sel) {
@@ -2104,6 +2105,7 @@ struct fql_engine {
         const bool lanes3 = lanes3_env && !visual && !split_build;
         const int fill_lane = lanes3 ? 2 : 1;
         if (!split_build) fill_lane_full = fill_lane;
+        wide_tiles = lanes3;
         place("os", 1, true);
         // one-step actor on [next_obs|eps1 ; obs|z ; obs|eps2]  (agents/fql.py:25,65,82)
         emit_forward(pr, p_os, with_grads, GF_OS_SCATTER, X_ct, X_c2);
