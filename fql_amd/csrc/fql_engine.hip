@@ -2117,7 +2117,7 @@ struct fql_engine {
             op.writes = {I_MSE};
             push(pr, op);
         }
-        place("c1", fill_lane, true);
+        place("c1f", fill_lane, true);   // (forward and loss / backward placed separately: FQL_LANE_c1f / FQL_LANE_c1)
         // critic(obs, actions) with grad params; target critic(next_obs, next_actions)  (fql.py:28,36)
         for (int e = 0; e < 2; ++e) emit_forward(pr, p_c1[e], with_grads);
         // three lanes: the target-critic pass rides on lane 1 (its action block comes from the one-step forward there, and lane 1 is otherwise
@@ -2152,8 +2152,9 @@ struct fql_engine {
             emit_encoder_backward(pr, eb_c, 0, B, p_c1[0].dx0, p_c1[1].dx0, nets[NET_C0].in_p());
         }
         // BC flow-matching pass (fql.py:52-59)
-        place("bc", fill_lane, true);
+        place("bcf", fill_lane, true);
         emit_forward(pr, p_bc, with_grads);
+        place("bc", fill_lane, true);
         {
             Op op{};
             op.type = OP_LOSS_BC;
