@@ -184,8 +184,46 @@ def test_data_parallel_wrapper_with_rccl_at_world_size_one(overlap):
         for k in ia:
             assert abs(ia[k] - ib[k]) <= 1e-6 * max(1.0, abs(ia[k])), (k, ia[k], ib[k])
         pa, pb = (dict(O.tree_leaves_with_path(x.get_params())) for x in (a, b))
-        for p in pa:
-            np.testing.assert_allclose(pb[p], pa[p], rtol=0, atol=1e-7, err_msg=p)
+        for p in pa:   # (the fused three-lane program uses 32 x 64 tiles throughout, the begin / end programs pick per launch: LN partial
+            #  sums fold in a different order, last-bit differences after three Adam steps)
+            np.testing.assert_allclose(pb[p], pa[p], rtol=0, atol=1e-6, err_msg=p)
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('overlap', [True, False])
+def test_two_processes_on_one_gpu_equal_one_step_on_the_concatenated_batch(tmp_path, overlap):
+    """DataParallelFQL end to end with TWO real ranks (two processes, gloo, both on cuda:0): state broadcast from rank 0 (parameters,
+    Adam moments, counters), physical shards, per-rank indices inside the shard, bucketed (overlapped) or single all-reduce,
+    per-bucket Adam - against ONE engine stepping on the concatenated 2B batches from the same start."""
+    import os
+    import subprocess
+    import sys
+    import fql_amd
+    od, ad, B = 29, 8, 32
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = str(29600 + (os.getpid() % 200) + (50 if overlap else 0))
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, 'tests', 'dp_worker.py'), str(r), port, str(tmp_path), str(int(overlap))],
+                              cwd=root) for r in range(2)]
+    rcs = [p.wait(timeout=240) for p in procs]
+    assert rcs == [0, 0], rcs
+    # the reference: one engine, same start, batch = [rank 0's rows ; rank 1's rows] of the global dataset
+    cfg, ds, _, _ = make_problem(od, ad, B, (64, 64, 64, 64), seed=71)
+    cfg2 = dict(cfg); cfg2['batch_size'] = 2 * B
+    one = fql_amd.FQLAgent.create(0, ds['observations'][:1], ds['actions'][:1], cfg)
+    one.set_params(randomize_params(one.get_params(), seed=72))
+    one.update(O.sample_batch(ds, np.arange(B)), noise=O.make_noise(B, ad, 73))
+    n = len(ds['observations'])
+    for step in range(3):
+        idx = np.random.default_rng(100 + step).integers(0, n // 2, size=2 * B)
+        idx_global = np.concatenate([idx[:B], n // 2 + idx[B:]])          # rank 1's shard starts at n / 2
+        one.update(O.sample_batch(ds, idx_global), noise=O.make_noise(2 * B, ad, 200 + step))
+    want = dict(O.tree_leaves_with_path(one.get_params()))
+    got = [np.load(os.path.join(tmp_path, f'rank{r}.npz')) for r in range(2)]
+    for p, w in want.items():
+        k = p.replace('/', '|')
+        np.testing.assert_array_equal(got[0][k], got[1][k], err_msg=p)     # replicas stay bit-identical
+        np.testing.assert_allclose(got[0][k], w, rtol=0, atol=2e-6, err_msg=p)
+    x0, x1 = (np.load(os.path.join(tmp_path, f'xbc{r}.npy')) for r in range(2))
+    assert not np.array_equal(x0, x1)                                      # different rows / noise per rank from the same seed
