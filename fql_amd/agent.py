@@ -352,6 +352,7 @@ class FQLAgent:
             nf = _Arg(dataset['next_observations'], fshape, u8=True)
             rest = [_Arg(dataset[k]) for k in ('actions', 'rewards', 'masks', 'terminals')]
             self._check(self._lib.fql_dataset_upload_frames(self._h, n, fr.ptr, nf.ptr, *[a.ptr for a in rest], fs, pa))
+            self._frame_stack = fs     # (remembered for the shape check of later ring inserts)
             return
         n = int(len(dataset['observations']))
         cap = int(capacity) if capacity is not None else max(n, 1)
@@ -372,14 +373,20 @@ class FQLAgent:
         """ReplayBuffer.add_transition (utils/datasets.py:483-491) into the dataset ring (replay=False: the dataset IS the replay
         buffer, main.py:111-115) or into the separate replay ring (replay=True, balanced sampling).  Visual agents pass single uint8
         frames [H, W, C / frame_stack] as observations / next_observations."""
-        a = _Arg(transition['actions'])
+        a = _Arg(transition['actions'], (self.config['action_dim'],))
         r, m = float(transition['rewards']), float(transition['masks'])
         if len(self.config['ob_dims']) == 3:
+            H, W, Cc = self.config['ob_dims']
+            fs = int(getattr(self, '_frame_stack', 0) or 0)
             fr = _Arg(transition['observations'], u8=True); nf = _Arg(transition['next_observations'], u8=True)
+            nel = fr.keep.numel() if hasattr(fr.keep, 'numel') else fr.keep.size
+            if fs and nel != H * W * (Cc // fs):
+                raise ValueError(f'expected one uint8 frame of {H}x{W}x{Cc // fs}, got {nel} elements')
             f = self._lib.fql_replay_add_frames if replay else self._lib.fql_dataset_add_frames
             self._check(f(self._h, fr.ptr, nf.ptr, a.ptr, r, m))
             return
-        o = _Arg(transition['observations']); no = _Arg(transition['next_observations'])
+        od = self.config['ob_dims'][0]
+        o = _Arg(transition['observations'], (od,)); no = _Arg(transition['next_observations'], (od,))   # (raises on a wrong element count)
         f = self._lib.fql_replay_add if replay else self._lib.fql_dataset_add
         self._check(f(self._h, o.ptr, a.ptr, r, m, no.ptr))
 

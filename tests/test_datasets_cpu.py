@@ -66,3 +66,47 @@ def test_frame_stack_and_augment_follow_the_reference():
     np.random.seed(0)
     b2 = ds.sample(5)
     assert b2['observations'].shape == (5, 8, 8, 9) and b2['observations'].dtype == np.uint8
+
+
+class _FakeAgent:
+    """Records what the host mirror asks of the engine (fql_amd/datasets.py attach / add_transition paths)."""
+
+    def __init__(self):
+        self.calls = []
+
+    def upload_dataset(self, ds, **kw):
+        self.calls.append(('upload', len(ds['observations']), kw))
+
+    def reserve_dataset(self, cap):
+        self.calls.append(('reserve', cap))
+
+    def create_replay_buffer(self, size):
+        self.calls.append(('replay_create', size))
+
+    def add_transition(self, tr, replay=False):
+        self.calls.append(('add', bool(replay), float(tr['rewards'])))
+
+
+def test_replay_buffer_attach_modes_drive_the_engine_as_main_py_does():
+    """main.py:111-115 (the dataset IS the ring) and :106-109 (a separate, initially empty ring for balanced sampling)."""
+    init = O.make_synthetic_dataset(6, 5, 2, seed=1)
+    tr = {k: (np.ones(v.shape[1:], v.dtype) if v.ndim > 1 else v.dtype.type(3)) for k, v in init.items()}
+    ag = _FakeAgent()
+    rb = ReplayBuffer.create_from_initial_dataset(init, size=8).attach(ag)
+    rb.add_transition(tr)
+    assert ag.calls == [('upload', 6, {'capacity': 8}), ('add', False, 3.0)]
+    ag2 = _FakeAgent()
+    rb2 = ReplayBuffer.create({k: v[0] for k, v in init.items()}, size=4)
+    rb2.add_transition(tr)                                   # a row held before attaching is replayed into the device ring
+    rb2.attach(ag2, replay=True)
+    rb2.add_transition(tr)
+    assert ag2.calls == [('replay_create', 4), ('add', True, 3.0), ('add', True, 3.0)]
+    assert (rb2.size, rb2.pointer) == (2, 2)
+    # frames: upload the rows held, then grow the device ring to max_size
+    n, hw = 5, 8
+    fr = dict(observations=np.zeros((n, hw, hw, 3), np.uint8), next_observations=np.zeros((n, hw, hw, 3), np.uint8),
+              terminals=np.zeros(n, np.float32), masks=np.ones(n, np.float32), actions=np.zeros((n, 2), np.float32), rewards=np.zeros(n, np.float32))
+    ag3 = _FakeAgent()
+    r3 = ReplayBuffer.create_from_initial_dataset(fr, size=9); r3.frame_stack = 3; r3.p_aug = 0.5
+    r3.attach(ag3)
+    assert ag3.calls == [('upload', 5, {'frame_stack': 3, 'p_aug': 0.5}), ('reserve', 9)]

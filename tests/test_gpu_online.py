@@ -136,3 +136,43 @@ def test_frames_ring_insert_and_balanced_frames_batch():
     assert ja == jb
     _, jc = a.update_balanced(B, want_info=True)          # engine RNG: indices, one coin per half, offsets
     assert all(np.isfinite(v) for v in jc.values())
+
+
+def test_reserve_turns_an_uploaded_state_dataset_into_a_ring_and_error_paths():
+    """fql_dataset_reserve on a state dataset (ReplayBuffer.create_from_initial_dataset, main.py:111-115) + the refusals of the N4 entry points."""
+    import fql_amd
+    from fql_amd.datasets import ReplayBuffer
+    od, ad, B = 7, 3, 16
+    cfg, ds, batch, noise = make_problem(od, ad, B, (32, 32), seed=51)
+    a = fql_amd.FQLAgent.create(3, batch['observations'][:1], batch['actions'][:1], cfg)
+    b = fql_amd.FQLAgent.create(3, batch['observations'][:1], batch['actions'][:1], cfg)
+    n = 40
+    init = {k: v[:n].copy() for k, v in ds.items()}
+    a.upload_dataset(init)                                  # capacity = n
+    with pytest.raises(ValueError):
+        a.reserve_dataset(n - 1)                            # cannot shrink
+    a.reserve_dataset(48)
+    assert a.dataset_size() == (n, n)
+    rb = ReplayBuffer.create_from_initial_dataset(init, size=48)      # host mirror, not attached: the expected contents
+    rng = np.random.default_rng(52)
+    for _ in range(13):                                     # 8 fill rows 40..47, then 5 overwrite rows 0..4
+        t = _transition(rng, od, ad)
+        a.add_transition(t); rb.add_transition(t)
+    assert a.dataset_size() == (rb.size, rb.pointer) == (47, 5)
+    idx = np.array([0, 4, 5, 39, 40, 46] + list(rng.integers(0, 47, size=B - 6)))
+    _, ia = a.update_from_dataset(B, idxs=idx, noise=noise, want_info=True)
+    _, ib = b.update(rb.sample(B, idxs=idx), noise=noise)
+    assert ia == ib
+    # refusals
+    with pytest.raises(ValueError):
+        a.update_balanced(B)                                # no replay ring
+    a.create_replay_buffer(4)
+    with pytest.raises(ValueError):
+        a.update_balanced(B)                                # empty ring
+    a.add_transition(_transition(rng, od, ad), replay=True)
+    a.update_balanced(B)                                    # one row is enough (every replay index is 0)
+    np.testing.assert_array_equal(_workspace(a, 5).reshape(-1)[B // 2:], _workspace(a, 5).reshape(-1)[B // 2])
+    with pytest.raises(ValueError):
+        a.update_balanced(B, idxs=(np.zeros(B // 2, np.int64), np.zeros(3, np.int64)))   # wrong index count
+    with pytest.raises(ValueError):
+        a.add_transition(dict(_transition(rng, od, ad), observations=np.zeros((4, 4, 3), np.uint8)), replay=True)   # a frame into a state ring

@@ -105,3 +105,18 @@ def test_uncapturable_lane_placement_is_refused_not_crashed():
     agent = fql_amd.FQLAgent.create(0, batch['observations'][:1], batch['actions'][:1], cfg)   # the default three-lane program
     agent.update(batch, noise=noise)
     assert agent.stats()['launches_per_update'] > 0
+
+
+def test_threaded_eager_lane_executor_passes_the_parity_cases():
+    """FQL_NO_GRAPH=3 (run_threaded: one host thread per extra lane, cross-lane order through per-launch sequence numbers + events, nothing
+    captured): the same parity cases as the captured graph, in a process of its own (the mode is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FQL_NO_GRAPH='3')
+    r = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_parity.py', '-q', '-m', 'gpu', '-x', '-k',
+                        'test_total_loss_and_update_match_oracle or test_full_size_config_one_update'],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout
