@@ -4,6 +4,9 @@
 // the fp32 matrix cores: rows = output pixels, columns = output channels (16 or 32), K = 9 taps x input channels.
 #pragma once
 #include "fql_kernels.h"
+#ifndef FQL_CWG_WAVES
+#define FQL_CWG_WAVES 3   // min waves per SIMD of the convolution weight-gradient kernel: 165 registers, three workgroups per CU
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // conv3x3 (stride 1, zero padding 1), forward and data-gradient form.
@@ -42,6 +45,7 @@ struct ConvTile {
     const void* in;
     float* in_s;
     int H, W, Ci, Ci_real, R, in_mode, CS, PW, tid;
+    bool is_u8;   // uint8 input (in_mode == 2); a compile-time constant at every use, so the other staging path and its registers fold away
     static constexpr int NU8 = 4;   // dwords per thread on the uint8 path: (R + 2) W C / 4 / 256 <= 4 (W C <= 1152 at R = 1, 576 at R = 2)
     f32x4 pre[NF];
     unsigned prew[NU8];
@@ -49,7 +53,7 @@ struct ConvTile {
     int f_lds[NF], f_g[NF], f_rr[NF];   // float path: LDS offset, offset inside an image row, tile row (-1: not this thread's); f_g < 0: halo column
     int y0;
     __device__ __forceinline__ void init() {
-        if (in_mode == 2) {
+        if (is_u8) {
             const int total = (R + 2) * PW * CS;
             for (int e = tid; e < total; e += FQL_THREADS) in_s[e] = 0.f;
             const int dpr = (W * Ci_real) >> 2, tdw = (R + 2) * dpr;
@@ -78,7 +82,7 @@ struct ConvTile {
     }
     __device__ __forceinline__ void fetch(int n, int y0_) {
         y0 = y0_;
-        if (in_mode == 2) {
+        if (is_u8) {
             const int dpr = (W * Ci_real) >> 2, total = (R + 2) * dpr;   // dwords per image row
             const unsigned* src = (const unsigned*)((const unsigned char*)in + (size_t)n * H * W * Ci_real);
 #pragma unroll
@@ -98,7 +102,7 @@ struct ConvTile {
         }
     }
     __device__ __forceinline__ void commit() {
-        if (in_mode == 2) {
+        if (is_u8) {
             const int dpr = (W * Ci_real) >> 2, total = (R + 2) * dpr;
 #pragma unroll
             for (int i = 0; i < NU8; ++i) {
@@ -137,7 +141,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
     const int nblocks = P.N * blocks_per_img;
     const int wg = (int)blockIdx.x - P.tile0, nwg = P.nwg;   // this task's workgroups walk its row blocks with stride nwg
     ConvTile T;
-    T.in = P.in; T.in_s = in_s; T.H = H; T.W = W; T.Ci = Ci; T.Ci_real = P.Ci_real; T.R = R; T.in_mode = P.in_mode; T.CS = CS; T.PW = PW; T.tid = tid;
+    T.in = P.in; T.in_s = in_s; T.H = H; T.W = W; T.Ci = Ci; T.Ci_real = P.Ci_real; T.R = R; T.CS = CS; T.PW = PW; T.tid = tid;
+    T.in_mode = PIPE ? 2 : P.in_mode; T.is_u8 = PIPE;   // the pipelined body is the uint8 first layer only: a constant here lets the float staging path (and its registers) fold away
     if constexpr (PIPE) {
         T.init();
         T.fetch(wg / blocks_per_img, (wg % blocks_per_img) * R);
@@ -253,11 +258,10 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_conv3x3_kernel(const ConvArgs
     if (P.Co == 32) conv_body<2, false>(P, lds);
     else conv_body<1, false>(P, lds);
 }
-__global__ __launch_bounds__(FQL_THREADS) void fql_conv3x3_u8_kernel(const ConvArgs* __restrict__ tasks, int ntasks) {   // in_mode 2
+__global__ __launch_bounds__(FQL_THREADS, 3) void fql_conv3x3_u8_kernel(const ConvArgs* __restrict__ tasks, int ntasks) {   // in_mode 2
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const ConvArgs& P = tasks[find_task(tasks, ntasks, blockIdx.x)];
-    if (P.Co == 32) conv_body<2, true>(P, lds);
-    else conv_body<1, true>(P, lds);
+    conv_body<1, true>(P, lds);   // the first convolution of every supported encoder has 16 output channels (checked where the op is emitted)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -276,7 +280,7 @@ struct ConvWgradArgs {
     int tile0, nwg;
 };
 
-template <int CI_TILES, int CO_TILES>
+template <int CI_TILES, int CO_TILES, bool U8>
 __device__ __forceinline__ void conv_wgrad_body(const ConvWgradArgs& P, float* lds) {
     constexpr int NUNITS = 9 * CI_TILES, NU = (NUNITS + 3) / 4;  // units per wave (round-robin: unit = wave + 4 k)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -289,6 +293,7 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradArgs& P, float* l
     const int ntiles = R * W / 16;
     ConvTile T;
     T.in = P.in; T.in_s = in_s; T.H = H; T.W = W; T.Ci = Ci; T.Ci_real = P.Ci_real; T.R = R; T.in_mode = P.in_mode; T.CS = CS; T.PW = PW; T.tid = tid;
+    T.is_u8 = U8;
     constexpr int ND = 4;   // dOut float4 per thread: R W Co / 4 / 256 <= 128 * 8 / 256
     f32x4 dpre[ND];
     const int dc4 = Co >> 2, dtotal = R * W * dc4;
@@ -392,13 +397,14 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradArgs& P, float* l
     }
 }
 
-__global__ __launch_bounds__(FQL_THREADS) void fql_conv_wgrad_kernel(const ConvWgradArgs* __restrict__ tasks, int ntasks) {
+__global__ __launch_bounds__(FQL_THREADS, FQL_CWG_WAVES) void fql_conv_wgrad_kernel(const ConvWgradArgs* __restrict__ tasks, int ntasks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const ConvWgradArgs& P = tasks[find_task(tasks, ntasks, blockIdx.x)];
-    if (P.Ci == 32 && P.Co == 32) conv_wgrad_body<2, 2>(P, lds);
-    else if (P.Ci == 16 && P.Co == 32) conv_wgrad_body<1, 2>(P, lds);
-    else if (P.Ci == 32 && P.Co == 16) conv_wgrad_body<2, 1>(P, lds);
-    else conv_wgrad_body<1, 1>(P, lds);
+    if (P.in_mode == 2) conv_wgrad_body<1, 1, true>(P, lds);   // the uint8 first layer (<= 16 channels in, 16 out: checked at emit)
+    else if (P.Ci == 32 && P.Co == 32) conv_wgrad_body<2, 2, false>(P, lds);
+    else if (P.Ci == 16 && P.Co == 32) conv_wgrad_body<1, 2, false>(P, lds);
+    else if (P.Ci == 32 && P.Co == 16) conv_wgrad_body<2, 1, false>(P, lds);
+    else conv_wgrad_body<1, 1, false>(P, lds);
 }
 
 // dK (arena layout [9][Cw_rows][Co]) and db from the per-workgroup partials.  One workgroup = 64 consecutive elements; its

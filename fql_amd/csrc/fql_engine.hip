@@ -720,6 +720,7 @@ struct fql_engine {
                    float* out, const void* out_id, float* out_relu, const float* mask, const void* mask_id, const float* add, const void* add_id) {
         Op op{};
         op.type = in_mode == 2 ? OP_CONV_U8 : OP_CONV;
+        if (in_mode == 2 && (transposed || c.cout != 16)) invalid("uint8 convolution kernel: 16 output channels expected (got %d)", c.cout);
         ConvArgs& a = op.conv;
         a.in = in; a.Wl = transposed ? c.Wb : c.Wf; a.bias = transposed ? nullptr : P + c.b;
         a.out = out; a.out_relu = out_relu; a.mask = mask; a.add = add;
@@ -801,9 +802,11 @@ struct fql_engine {
         float* wp = b.wpart.at(P + c.w);
         a.in = in; a.dout = dout; a.partial = wp;
         a.N = n; a.H = H; a.W = W; a.Ci = pad16c(c.cin); a.Ci_real = c.cin; a.Co = c.cout; a.in_mode = in_mode;
+        if (in_mode == 2 && (a.Ci != 16 || a.Co != 16)) invalid("uint8 convolution weight gradient: <= 16 input channels and 16 output channels expected (got %d -> %d)", c.cin, c.cout);
         a.R = conv_rows(H, W, a.Ci, a.Co, true);
         a.nblocks = n * (H / a.R);
-        op.cw_grid = std::min(a.nblocks, 256);
+        static const int cwg_env = getenv("FQL_CWG_GRID") ? atoi(getenv("FQL_CWG_GRID")) : 256;   // persistent workgroups per weight-gradient task
+        op.cw_grid = std::min(a.nblocks, cwg_env);
         op.reads = {in_id, dout_id};
         op.writes = {wp};
         push(pr, op);
@@ -1462,11 +1465,17 @@ struct fql_engine {
                     };
                     if (ty == OP_CONV || ty == OP_CONV_U8) {
                         std::vector<ConvArgs> tb;
+                        long long nb_all = 0;
+                        for (const Op* o : sel) nb_all += (long long)o->conv.N * (o->conv.H / o->conv.R);
+                        // persistent uint8 kernel: its 162 registers (launch bound 3 waves per SIMD) allow three workgroups per CU; exactly that many are launched (a fourth
+                        // round of workgroups would run alone) and dealt to the tasks in proportion to their row blocks (the one-step pass
+                        // holds [obs ; next_obs], twice the images of the others), rounded DOWN so the total never exceeds the resident set
+                        static const int u8_per_cu = getenv("FQL_U8_WGS_PER_CU") ? atoi(getenv("FQL_U8_WGS_PER_CU")) : 3;
                         for (const Op* o : sel) {
                             ConvArgs a = o->conv;
                             const int nb = a.N * (a.H / a.R);
                             a.tile0 = tile;
-                            a.nwg = ty == OP_CONV_U8 ? std::min(nb, std::max(1, 3 * num_cus / (int)sel.size())) : nb;
+                            a.nwg = ty == OP_CONV_U8 ? std::min(nb, std::max(1, (int)(((long long)u8_per_cu * num_cus * nb) / nb_all))) : nb;
                             tile += a.nwg;
                             L.lds = std::max(L.lds, ((size_t)(a.R + 2) * (a.W + 2) * (a.Ci + 4) + (size_t)a.Co * (9 * a.Ci + 4)) * sizeof(float));
                             tb.push_back(a);
