@@ -4,6 +4,9 @@
 // the fp32 matrix cores: rows = output pixels, columns = output channels (16 or 32), K = 9 taps x input channels.
 #pragma once
 #include "fql_kernels.h"
+#ifndef FQL_CONV_WAVES
+#define FQL_CONV_WAVES 3   // min waves per SIMD of the float convolution kernel (116 registers: up to 4)
+#endif
 #ifndef FQL_CWG_WAVES
 #define FQL_CWG_WAVES 3   // min waves per SIMD of the convolution weight-gradient kernel: 165 registers, three workgroups per CU
 #endif
@@ -252,7 +255,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
 }
 
 // One launch = every convolution of one scheduling level (e.g. the same layer of the four encoder passes): task table in HBM.
-__global__ __launch_bounds__(FQL_THREADS) void fql_conv3x3_kernel(const ConvArgs* __restrict__ tasks, int ntasks) {
+__global__ __launch_bounds__(FQL_THREADS, FQL_CONV_WAVES) void fql_conv3x3_kernel(const ConvArgs* __restrict__ tasks, int ntasks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const ConvArgs& P = tasks[find_task(tasks, ntasks, blockIdx.x)];
     if (P.Co == 32) conv_body<2, false>(P, lds);

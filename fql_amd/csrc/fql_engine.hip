@@ -1475,7 +1475,10 @@ struct fql_engine {
                             ConvArgs a = o->conv;
                             const int nb = a.N * (a.H / a.R);
                             a.tile0 = tile;
-                            a.nwg = ty == OP_CONV_U8 ? std::min(nb, std::max(1, (int)(((long long)u8_per_cu * num_cus * nb) / nb_all))) : nb;
+                            // float layers: a workgroup per row block by default; FQL_CONV_WGS_PER_CU=k makes them persistent too (measured: +-1 %)
+                            static const int conv_per_cu = getenv("FQL_CONV_WGS_PER_CU") ? atoi(getenv("FQL_CONV_WGS_PER_CU")) : 0;
+                            const int per_cu = ty == OP_CONV_U8 ? u8_per_cu : conv_per_cu;
+                            a.nwg = per_cu > 0 ? std::min(nb, std::max(1, (int)(((long long)per_cu * num_cus * nb) / nb_all))) : nb;
                             tile += a.nwg;
                             L.lds = std::max(L.lds, ((size_t)(a.R + 2) * (a.W + 2) * (a.Ci + 4) + (size_t)a.Co * (9 * a.Ci + 4)) * sizeof(float));
                             tb.push_back(a);
@@ -1619,6 +1622,8 @@ struct fql_engine {
                 const double H = cfg.actor_hidden[0];
                 m = (double)o.chain.M * H * H + (o.chain.variant == 0 ? (double)o.chain.M * 16.0 * H : 0.0) + (o.chain.variant == 2 ? (double)o.chain.M * H * o.chain.ap : 0.0);
             }
+            else if (o.type == OP_CONV || o.type == OP_CONV_U8) m = (double)o.conv.N * o.conv.H * o.conv.W * 9.0 * (o.conv.transposed ? o.conv.Ci : o.conv.Ci_real) * o.conv.Co;
+            else if (o.type == OP_CONV_WGRAD) m = (double)o.cw.N * o.cw.H * o.cw.W * 9.0 * o.cw.Ci_real * o.cw.Co;
             pr.launches[li].macs += m;
         }
         // cross-lane edges: a launch waits for the latest launch of the other lane it depends on (lane streams
