@@ -139,6 +139,9 @@ def main():
     ap.add_argument('--obs-dim', type=int, default=29, help='state workload: observation width (configs[2] uses 40)')
     ap.add_argument('--act-dim', type=int, default=8, help='state workload: action width (configs[2] uses 4)')
     ap.add_argument('--alpha', type=float, default=None, help='BC coefficient (default 10 for the state workload, 300 visual)')
+    ap.add_argument('--precision', choices=['fp32', 'bf16x3'], default=os.environ.get('FQL_BENCH_PRECISION', 'fp32'),
+                    help="fp32 = fp32 matrix cores (the headline); bf16x3 = split-bf16 products on the bf16 matrix cores, fp32 accumulate "
+                         "(fql_config.precision = 2; reported against the bf16 peak / 3)")
     args = ap.parse_args()
 
     import torch
@@ -177,7 +180,7 @@ def main():
         agent = fql_amd.FQLAgent.create(seed, np.zeros((1, 64, 64, 9), np.uint8), ds['actions'][:1], cfg)
         up_kw = dict(frame_stack=3, p_aug=0.5)
     else:
-        cfg.update(alpha=10.0 if args.alpha is None else args.alpha, batch_size=B)
+        cfg.update(alpha=10.0 if args.alpha is None else args.alpha, batch_size=B, precision=args.precision)
         ds = make_synthetic_dataset(args.rows, od, ad, seed=0)
         agent = fql_amd.FQLAgent.create(seed, ds['observations'][:1], ds['actions'][:1], cfg)
         up_kw = {}

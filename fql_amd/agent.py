@@ -169,6 +169,10 @@ class FQLAgent:
         c.flow_steps = int(cfg['flow_steps'])
         c.normalize_q_loss = int(bool(cfg['normalize_q_loss']))
         c.batch_size = int(cfg['batch_size'])
+        prec = cfg.get('precision', 'fp32')
+        if prec not in ('fp32', 'bf16x3', 0, 2):
+            raise ValueError(f"precision must be 'fp32' or 'bf16x3', got {prec!r}")
+        c.precision = 2 if prec in ('bf16x3', 2) else 0
         h = C.c_void_p()
         rc = lib.fql_create(C.byref(c), int(seed) & 0xFFFFFFFFFFFFFFFF, C.byref(h))
         _cabi.check(lib, None, rc)

@@ -34,5 +34,7 @@ def get_config():
         encoder=None,
         rng='engine',  # not a reference key: 'engine' = device Philox noise; 'jax' / 'jax_partitionable' = the reference's key derivation with
                        # JAX's original / partitionable threefry layout (keys on the host, tensors on the device: fql_noise_from_jax_keys)
+        precision='fp32',  # not a reference key: 'fp32' = fp32 matrix cores (exact fma chains); 'bf16x3' = split-bf16 products on the bf16 matrix
+                           # cores with fp32 accumulation (fql_config.precision = 2; ~1e-5 relative on the dense products)
         rng_device=True,  # not a reference key: False draws the JAX-mode tensors on the host (fql_amd/jax_prng.py) and ships them H2D
     )

@@ -1378,7 +1378,7 @@ struct fql_engine {
                         double other = 0.0;   // in units of a 32 x 32 x 512 tile
                         for (const Op* o : sel) {
                             const GemmTask& t = o->gemm;
-                            const bool big = ri_env ? ri_env == 2 : (t.M >= 1024 && t.M % 64 == 0);
+                            const bool big = cfg.precision == 2 ? false : ri_env ? ri_env == 2 : (t.M >= 1024 && t.M % 64 == 0);
                             if (big) other += 4.0 * (t.M / 64) * (t.N / 64) * t.K / 512.0;
                             else t64 += (t.M / 32) * (t.N / 64);
                         }
@@ -1391,7 +1391,7 @@ struct fql_engine {
                     }
                     for (const Op* o : sel) {
                         GemmTask t = o->gemm;
-                        const int ri_t = ri_env ? ri_env : (t.M >= 1024 && t.M % 64 == 0 ? 2 : 1);
+                        const int ri_t = cfg.precision == 2 ? 1 : ri_env ? ri_env : (t.M >= 1024 && t.M % 64 == 0 ? 2 : 1);   // split bodies are 32-row tiles
                         ri = std::max(ri, ri_t);
                         if (ri_t == 2) L.tmt2 = true;
                         t.tmt = ri_t;
@@ -1432,6 +1432,7 @@ struct fql_engine {
                     L.ntasks = (int)tg.size(); L.n_w = (int)tw.size(); L.n_l = (int)tl.size();
                     L.lds = sizeof(float) * (tg.empty() ? (size_t)FQL_WGRAD_LDS_FLOATS
                                              : ri == 2 ? (size_t)(2 * (32 * ri + 64) * 68 + 256)
+                                             : cfg.precision == 2 ? (size_t)FQL_TILE_SPLIT_LDS_FLOATS(nj)
                                              : nj == 1 ? (size_t)(2 * 32 * 68 + 2 * 64 * 36 + 128) : (size_t)(2 * 32 * 68 + 2 * 64 * 68 + 128));
                     L.lds = std::max(L.lds, sizeof(float) * (size_t)((selw.empty() ? 0 : FQL_WGRAD_LDS_FLOATS)));
                     auto up = [&](const void* src, size_t bytes) -> void* {
@@ -1689,6 +1690,10 @@ struct fql_engine {
                     FQL_LAUNCH(fql_side_big_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks,
                                        (const WgradTask*)L.table_w, L.n_w, (const LnBwdTask*)L.table_l, L.n_l, L.tile_w, L.tile_l,
                                        (const MiscTask*)L.table_m, L.tile_m, 0, tl);
+                else if (L.side && cfg.precision == 2)
+                    FQL_LAUNCH(fql_side_split_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks,
+                                       (const WgradTask*)L.table_w, L.n_w, (const LnBwdTask*)L.table_l, L.n_l, L.tile_w, L.tile_l,
+                                       (const MiscTask*)L.table_m, L.tile_m, side_prio, tl);
                 else if (L.side)
                     FQL_LAUNCH(fql_side_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks,
                                        (const WgradTask*)L.table_w, L.n_w, (const LnBwdTask*)L.table_l, L.n_l, L.tile_w, L.tile_l,
@@ -2919,7 +2924,7 @@ int fql_create(const fql_config* cfg, uint64_t seed, fql_handle* out) {
             invalid("hidden layer counts must be in [1, %d]", FQL_MAX_HIDDEN);
         if (cfg->flow_steps < 1) invalid("flow_steps must be >= 1");
         if (cfg->q_agg != 0 && cfg->q_agg != 1) invalid("q_agg must be 0 (mean) or 1 (min)");
-        if (cfg->precision != 0) invalid("precision %d not available (0 = fp32 MFMA)", cfg->precision);
+        if (cfg->precision != 0 && cfg->precision != 2) invalid("precision %d not available (0 = fp32 MFMA, 2 = bf16 x 3 split MFMA)", cfg->precision);
         HIP_CHECK(hipGetDevice(&h->device));
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, h->device));

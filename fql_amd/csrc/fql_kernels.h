@@ -23,6 +23,45 @@ __device__ __forceinline__ void stg4(float* p, f32x4 v) { *(FQL_GAS f32x4*)p = v
 
 #define FQL_THREADS 256
 
+// ------------------------------------------------------------------------------------------------
+// precision = 2 ("bf16x3", SURVEY 8b config key `precision`): an fp32 operand x is split into two bf16 values
+//   hi = bf16(x), lo = bf16(x - hi)            (both round-to-nearest-even; x - hi is exact in fp32)
+// and a product a b is evaluated as a_hi b_hi + (a_hi b_lo + a_lo b_hi) on the bf16 matrix cores
+// (v_mfma_f32_16x16x32_bf16, fp32 accumulation; the two small terms on an accumulator of their own).  What is dropped is
+// a_lo b_lo and the split's own residual: <= 2^-16 |a b| per product, ~2^-18 typical with signs that average out
+// (fp32 itself: 2^-24).  16 cycles per 16x16x32 MFMA against 32 per 16x16x4 fp32 MFMA: 3 x 16 cycles do the work of 8 x 32.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float x0, float x1) {   // {bf16(x0) in bits 0-15, bf16(x1) in bits 16-31}
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x0), "v"(x1));
+    return r;
+}
+__device__ __forceinline__ void bsplit2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    hi = cvt_pk_bf16(x0, x1);
+    const float h0 = __uint_as_float(hi << 16), h1 = __uint_as_float(hi & 0xffff0000u);
+    lo = cvt_pk_bf16(x0 - h0, x1 - h1);
+}
+__device__ __forceinline__ void bsplit4(const f32x4& v, u32x2& hi, u32x2& lo) {
+    unsigned h0, l0, h1, l1;
+    bsplit2(v[0], v[1], h0, l0);
+    bsplit2(v[2], v[3], h1, l1);
+    hi = u32x2{h0, h1};
+    lo = u32x2{l0, l1};
+}
+__device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const f32x4& acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+// transposed LDS read (ds_read_b64_tr_b16): within each group of 16 lanes, lane 4r + p supplies the address of row r, columns
+// 4p .. 4p+3 of a 4 x 16 block of 16-bit elements; lane i receives column i (element e = row e).  EXEC must be all ones.
+__device__ __forceinline__ u32x2 lds_read_tr16(const unsigned* p) {
+    typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)p));
+}
+
 // Diagnostics build (-DFQL_TIMELINE): every instrumented launch records the wall-clock (100 MHz) time of its first and last
 // workgroup entry and of its last exit, so the REAL overlapped schedule of the two lanes can be read back (rocprofv3 serialises
 // the graph's branches).  In the product build the marks compile to nothing; the launch id argument stays for one code path.
@@ -1163,10 +1202,238 @@ __device__ __forceinline__ void gemm32_body(const GemmTask& T, float* lds) {
 }
 #define FQL_TILE_LDS_FLOATS(NJ) (2 * 32 * G64_S + 2 * 64 * G64_S + 128)   /* upper bound over transb / NJ */
 
+// ------------------------------------------------------------------------------------------------
+// precision = 2: the same 32 x (32 NJ) tile with split-bf16 operands (see the top of this file).
+// Global loads, the two-chunk register pipeline, LayerNorm-at-store and the epilogue are those of gemm32_body; what changes is
+// what a chunk looks like in LDS and what the K loop issues:
+//   * every fp32 value is split ONCE, by the thread that stages it, into a hi and a lo bf16 plane (same bytes as the fp32 chunk);
+//   * A (and W^T for dgrads) planes are [row][64 k] with 32-word rows and no padding.  A lane's 16x16x32 fragment is 8 k values =
+//     ONE ds_read_b128 per plane; the 4-word slots of a row are XOR-swizzled with (row >> 1) & 7, which makes both the b128
+//     fragment reads (the hardware's 16-lane groups mix two k-quarters) and the b64 staging writes conflict-free
+//     (tools/lds_banks.py enumerates the bank of every lane under the rules of MI355X_MICROARCH.md);
+//   * the k order inside a 32-deep MFMA step is permuted - lane (c, q) owns k = 4q..4q+3 and 16+4q..16+4q+3 - identically for
+//     both operands (a contraction does not care).  That makes the forward pass's B operand, stored [k][n] as it arrives from the
+//     row-major kernel, readable with the hardware transpose ds_read_b64_tr_b16: a 32-lane half then covers 8 CONSECUTIVE k rows,
+//     which the 8-word column chunks XOR-swizzled by the row spread over all 64 banks (no padding either);
+//   * per 64-deep chunk a wave issues 2 x NJ x 3 MFMAs of 16 cycles (fp32 path: 16 NJ of 32 cycles); the hi x hi products
+//     accumulate in acc[j][0], the two cross terms in acc[j][1], summed in the epilogue.
+// ------------------------------------------------------------------------------------------------
+template <bool transb, int NJ>
+__device__ __forceinline__ void gemm32s_body(const GemmTask& T, float* lds_f) {
+    constexpr int TN = 32 * NJ;
+    constexpr int RW = TN / 2;                    // words per row of a [k][n] B plane
+    constexpr int BPL = transb ? TN * 32 : 64 * RW;   // words per B plane
+    constexpr int APL = 32 * 32;                  // words per A plane
+    constexpr int NB = 2 * NJ;                    // float4 per thread of a B chunk
+    unsigned* As = reinterpret_cast<unsigned*>(lds_f);   // [2 buffers][hi, lo][32 rows][32 words]
+    unsigned* Bs = As + 4 * APL;                          // [2 buffers][hi, lo][BPL]
+    float* part = reinterpret_cast<float*>(Bs + 4 * BPL); // [2 column halves][32][2] LN partial sums of the epilogue
+    const int local = (int)blockIdx.x - T.tile0;
+    const int tm = local / T.ntn, tn = local - tm * T.ntn;
+    const int row0 = tm * 32, n0 = tn * TN;
+    const int K = T.K;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int c = lane & 15, q = lane >> 4;
+    const int flags = T.flags;
+    const bool a_ln = (flags & GF_A_LN) != 0;
+    const bool ln_wr = (flags & GF_LN_WRITE) && tn == 0;
+    const int sr = tid >> 4, sc4 = tid & 15;      // A staging: rows sr, sr + 16; float4 column sc4 (k = 4 sc4 .. 4 sc4 + 3)
+    const int br0 = (transb || NJ == 2) ? sr : (tid >> 3), brs = (transb || NJ == 2) ? 16 : 32;
+    const int bc4 = (transb || NJ == 2) ? sc4 : (tid & 7);
+    const float* __restrict__ Ag = T.A + (size_t)(row0 + sr) * T.lda + 4 * sc4;
+    const float* __restrict__ Bg = transb ? T.B + (size_t)(n0 + br0) * T.ldb + 4 * bc4 : T.B + (size_t)br0 * T.ldb + n0 + 4 * bc4;
+    f32x4 ra0[2], rb0[NB], ra1[2], rb1[NB], lg0, lb0, lg1, lb1;
+    lg0 = lb0 = lg1 = lb1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto load_chunk = [&](f32x4 (&ra)[2], f32x4 (&rb)[NB], f32x4& lg, f32x4& lb, int k0) {   // K is a multiple of 64: no guards
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ra[i] = ldg4(Ag + (size_t)(16 * i) * T.lda + k0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = transb ? ldg4(Bg + (size_t)(brs * i) * T.ldb + k0) : ldg4(Bg + (size_t)(k0 + brs * i) * T.ldb);
+        if (a_ln) { lg = ldg4(T.ln_g + k0 + 4 * sc4); lb = ldg4(T.ln_b + k0 + 4 * sc4); }
+    };
+    const int nchunks = K >> 6;
+    load_chunk(ra0, rb0, lg0, lb0, 0);
+    if (nchunks > 1) load_chunk(ra1, rb1, lg1, lb1, 64);
+    float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f};
+    if (a_ln) {
+        const float inv = 1.0f / (float)T.ln_width;
+        float sm[2], sq[2];
+        ln_fold_partials<2>(T.aux2, row0 + sr, T.i0, sm, sq);   // T.i0 = K / 32 partials per row
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            mean[i] = sm[i] * inv;
+            const float var = fmaxf(0.0f, sq[i] * inv - mean[i] * mean[i]);
+            rstd[i] = 1.0f / sqrtf(var + 1e-6f);
+            if (ln_wr && sc4 == 0) { const int row = row0 + sr + 16 * i; stg(T.ln_stats + 2 * row, mean[i]); stg(T.ln_stats + 2 * row + 1, rstd[i]); }
+        }
+    }
+    // word offset, inside a 32-word [row][64 k] row, of the 4 k values a staging thread owns: 4-k block t = sc4 -> MFMA step
+    // kp = t >> 3, owner quarter q = t & 3, half h = (t >> 2) & 1 of that lane's 8 values; slot 4 kp + q is swizzled per row
+    const int st_slot = 4 * (sc4 >> 3) + (sc4 & 3), st_h = (sc4 >> 2) & 1;
+    auto rowk_word = [&](int row) { return row * 32 + 4 * (st_slot ^ ((row >> 1) & 7)) + 2 * st_h; };
+    auto store_chunk = [&](f32x4 (&ra)[2], const f32x4 (&rb)[NB], const f32x4& lg, const f32x4& lb, int k0, int buf) {
+        unsigned* ah = As + buf * 2 * APL;
+        unsigned* bh = Bs + buf * 2 * BPL;
+        if (a_ln) {   // utils/networks.py:58 on the rows of this chunk
+            const int k = k0 + 4 * sc4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = (ra[i][e] - mean[i]) * rstd[i] * lg[e] + lb[e];
+                    ra[i][e] = (k + e < T.ln_width) ? v : 0.f;
+                }
+                if (ln_wr) stg4(T.ln_xout + (size_t)(row0 + sr + 16 * i) * T.lda + k, ra[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            u32x2 hi, lo;
+            bsplit4(ra[i], hi, lo);
+            const int w = rowk_word(sr + 16 * i);
+            *reinterpret_cast<u32x2*>(ah + w) = hi;
+            *reinterpret_cast<u32x2*>(ah + APL + w) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            u32x2 hi, lo;
+            bsplit4(rb[i], hi, lo);
+            int w;
+            if (transb) w = rowk_word(br0 + brs * i);
+            else {   // [k][n] plane: row k = br0 + brs i, 4 columns n = 4 bc4 ..: 8-word chunk bc4 >> 2 swizzled by the row
+                const int k = br0 + brs * i;
+                const int key = (NJ == 2) ? ((k >> 1) & 3) : ((k >> 2) & 1);
+                w = k * RW + 8 * ((bc4 >> 2) ^ key) + 2 * (bc4 & 3);
+            }
+            *reinterpret_cast<u32x2*>(bh + w) = hi;
+            *reinterpret_cast<u32x2*>(bh + BPL + w) = lo;
+        }
+    };
+    f32x4 acc[NJ][2];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bias[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bias[j] = (flags & GF_BIAS) ? ldg(T.bias + n0 + (wc * NJ + j) * 16 + c) : 0.f;
+
+    // fragment addresses (words) that do not depend on the chunk
+    const int a_row = (16 * wr + c) * 32, sw = (c >> 1) & 7;
+    // transposed read: this lane supplies the address of row 4 q + qq (+ 16 h + 32 kp), columns 4 p .. 4 p + 3 of the wave's column tile
+    const int qq = c >> 2, p = c & 3;
+    const int tr_row = 4 * q + qq;
+    const int tr_key = (NJ == 2) ? ((tr_row >> 1) & 3) : ((tr_row >> 2) & 1);
+    auto compute = [&](int buf) {
+        const unsigned* ah = As + buf * 2 * APL;
+        const unsigned* bh = Bs + buf * 2 * BPL;
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp) {
+            const int slot = 4 * ((4 * kp + q) ^ sw);
+            const u32x4 fah = *reinterpret_cast<const u32x4*>(ah + a_row + slot);
+            const u32x4 fal = *reinterpret_cast<const u32x4*>(ah + APL + a_row + slot);
+            u32x4 fbh[NJ], fbl[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (transb) {
+                    const int brow = ((wc * NJ + j) * 16 + c) * 32;   // (row >> 1) & 7 == (c >> 1) & 7: the tile base is a multiple of 16
+                    fbh[j] = *reinterpret_cast<const u32x4*>(bh + brow + slot);
+                    fbl[j] = *reinterpret_cast<const u32x4*>(bh + BPL + brow + slot);
+                } else {
+                    const int w0 = (32 * kp + tr_row) * RW + 8 * ((wc * NJ + j) ^ tr_key) + 2 * p;
+                    const u32x2 h0 = lds_read_tr16(bh + w0), h1 = lds_read_tr16(bh + w0 + 16 * RW);
+                    const u32x2 l0 = lds_read_tr16(bh + BPL + w0), l1 = lds_read_tr16(bh + BPL + w0 + 16 * RW);
+                    fbh[j] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+                    fbl[j] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j][0] = mfma_bf16(fah, fbh[j], acc[j][0]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j][1] = mfma_bf16(fah, fbl[j], acc[j][1]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j][1] = mfma_bf16(fal, fbh[j], acc[j][1]);
+        }
+    };
+    // chunk ch computes from LDS slot ch & 1 while chunks ch+1 (registers) and ch+2 (in flight) follow
+    store_chunk(ra0, rb0, lg0, lb0, 0, 0);
+    if (nchunks > 2) load_chunk(ra0, rb0, lg0, lb0, 128);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ch += 2) {
+        compute(0);
+        if (ch + 1 < nchunks) store_chunk(ra1, rb1, lg1, lb1, 64 * (ch + 1), 1);
+        __syncthreads();
+        if (ch + 3 < nchunks) load_chunk(ra1, rb1, lg1, lb1, 64 * (ch + 3));
+        if (ch + 1 < nchunks) {
+            compute(1);
+            if (ch + 2 < nchunks) store_chunk(ra0, rb0, lg0, lb0, 64 * (ch + 2), 0);
+            __syncthreads();
+            if (ch + 4 < nchunks) load_chunk(ra0, rb0, lg0, lb0, 64 * (ch + 4));
+        }
+    }
+
+    // ---- epilogue (that of gemm32_body). C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
+    float s1[4], s2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = row0 + 16 * wr + 4 * q + r;
+        s1[r] = 0.f; s2[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + (wc * NJ + j) * 16 + c;
+            const size_t o = (size_t)row * T.ldc + n;
+            float v = acc[j][0][r] + acc[j][1][r] + bias[j];
+            if (flags & GF_SAVE_Z) { float gg, dg; gelu_both(v, gg, dg); stg(T.Zout + o, dg); v = (flags & GF_GELU) ? gg : v; }
+            else if (flags & GF_GELU) v = gelu_f(v);
+            if (flags & GF_GELUGRAD) v *= ldg(T.Zprev + o);
+            if (flags & GF_RELUGRAD) v = (ldg(T.Zprev + o) > 0.f) ? v : 0.f;
+            stg(T.C + o, v);
+            s1[r] += v; s2[r] += v * v;
+        }
+    }
+    if (flags & GF_LN_PART) {   // per-row (sum, sum of squares) of each 32-column half: T.i1 = N / 32 partials per row
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = s1[r], b = s2[r];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+            if (c == 0) {
+                const int rl = 16 * wr + 4 * q + r;
+                part[(wc * 32 + rl) * 2] = a;
+                part[(wc * 32 + rl) * 2 + 1] = b;
+            }
+        }
+        __syncthreads();
+        const int rs = (2 * T.i1 + 3) & ~3;
+        if (NJ == 2) {
+            if (tid < 64) {
+                const int half = tid >> 5, rl = tid & 31;
+                float* pp = T.aux + (size_t)(row0 + rl) * rs + 2 * (2 * tn + half);
+                stg(pp, part[(half * 32 + rl) * 2]);
+                stg(pp + 1, part[(half * 32 + rl) * 2 + 1]);
+            }
+        } else if (tid < 32) {
+            float* pp = T.aux + (size_t)(row0 + tid) * rs + 2 * tn;
+            stg(pp, part[tid * 2] + part[(32 + tid) * 2]);
+            stg(pp + 1, part[tid * 2 + 1] + part[(32 + tid) * 2 + 1]);
+        }
+    }
+}
+#define FQL_TILE_SPLIT_LDS_FLOATS(NJ) (4 * 32 * 32 + 4 * 32 * 32 * (NJ) + 128)
+
 // one throughput-lane tile task: T.tmt = 2 -> 64 x 64 tile (round-1 body; BIG launches only: it needs twice the registers, and
 // the 32-row shapes want three or four workgroups per CU), else 32 x (32 T.wk)
-template <bool BIG>
+template <bool BIG, bool SPLIT = false>
 __device__ __forceinline__ void gemm_tile_dispatch(const GemmTask& T, float* lds) {
+    if (SPLIT) {
+        if (T.wk == 2) {
+            if (T.flags & GF_TRANS_B) gemm32s_body<true, 2>(T, lds);
+            else gemm32s_body<false, 2>(T, lds);
+        } else {
+            if (T.flags & GF_TRANS_B) gemm32s_body<true, 1>(T, lds);
+            else gemm32s_body<false, 1>(T, lds);
+        }
+        return;
+    }
     if (BIG && T.tmt == 2) {
         if (T.flags & GF_TRANS_B) gemm64_body<true, 2>(T, lds);
         else gemm64_body<false, 2>(T, lds);
@@ -1262,6 +1529,95 @@ __device__ __forceinline__ void wgrad_body(const WgradTask& T, int bid, float* l
     }
 }
 #define FQL_WGRAD_LDS_FLOATS (4 * 4 * 64 * 4 + 4 * 64)
+// precision = 2 weight gradient: same tile geometry, LDS reduction and summation order over waves.  The 8 batch rows a lane holds
+// per chunk for X^T and for each dZ column tile are exactly one 16x16x32 operand each (the k order inside an MFMA step is free as
+// long as both operands share it), so a chunk is split in registers and multiplied with 3 x 4 bf16 MFMAs instead of 32 fp32 ones;
+// db stays an fp32 column sum.  Loads are branch-free (out-of-range steps / column tiles re-read a valid address and are zeroed).
+__device__ __forceinline__ void wgrad_split_body(const WgradTask& T, int bid, float* lds) {
+    float* red = lds;                    // [wave][tile][lane] float4
+    float (*redb)[64] = reinterpret_cast<float (*)[64]>(lds + 4 * 4 * 64 * 4);
+    const int local = bid - T.tile0;
+    const int tk = local / T.ntn, tn = local - tk * T.ntn;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = lane & 15, q = lane >> 4;
+    const int k0 = tk * 16, n0 = tn * 64;
+    const int ntv = min(4, (T.N - n0) >> 4);  // valid 16-column tiles in this workgroup
+    const int steps = T.M >> 4;               // MFMA steps (4 batch rows each) per wave
+    const size_t sx = (size_t)4 * T.ldx, sz = (size_t)4 * T.ldz;
+    const float* __restrict__ xp = T.X + (size_t)(4 * wave * steps + q) * T.ldx + k0 + c;   // A[i = kin][k = m]
+    const float* __restrict__ zp = T.dZ + (size_t)(4 * wave * steps + q) * T.ldz + n0 + c;  // B[k = m][j = n]
+    int toff[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) toff[t] = 16 * min(t, ntv - 1);
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    float a0[8], b0[32], a1[8], b1[32];
+    auto load = [&](float (&a)[8], float (&b)[32], int s0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int st = min(s0 + i, steps - 1);
+            a[i] = ldg(xp + st * sx);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b[4 * i + t] = ldg(zp + st * sz + toff[t]);
+        }
+    };
+    auto mma = [&](const float (&a)[8], const float (&b)[32], int s0) {
+        float av[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) av[i] = (s0 + i < steps) ? a[i] : 0.f;   // zero X rows: the products of a clamped step vanish
+        u32x4 ah, al;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { unsigned h, l; bsplit2(av[2 * i], av[2 * i + 1], h, l); ah[i] = h; al[i] = l; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            u32x4 bh, bl;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned h, l;
+                const float b0v = (s0 + 2 * i < steps && t < ntv) ? b[8 * i + t] : 0.f;
+                const float b1v = (s0 + 2 * i + 1 < steps && t < ntv) ? b[8 * i + 4 + t] : 0.f;
+                bs[t] += b0v + b1v;
+                bsplit2(b0v, b1v, h, l);
+                bh[i] = h; bl[i] = l;
+            }
+            acc[t] = mfma_bf16(al, bh, acc[t]);
+            acc[t] = mfma_bf16(ah, bl, acc[t]);
+            acc[t] = mfma_bf16(ah, bh, acc[t]);
+            __builtin_amdgcn_sched_barrier(0);   // keeps the compiler from hoisting every split in front of the MFMAs (spills)
+        }
+    };
+    load(a0, b0, 0);
+    for (int s = 0; s < steps; s += 16) {
+        if (s + 8 < steps) load(a1, b1, s + 8);
+        mma(a0, b0, s);
+        if (s + 8 < steps) {
+            if (s + 16 < steps) load(a0, b0, s + 16);
+            mma(a1, b1, s + 8);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        *reinterpret_cast<f32x4*>(&red[((wave * 4 + t) * 64 + lane) * 4]) = acc[t];
+        float v = bs[t];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (q == 0) redb[wave][16 * t + c] = v;
+    }
+    __syncthreads();
+    if (wave < ntv) {
+        f32x4 r = *reinterpret_cast<const f32x4*>(&red[((0 * 4 + wave) * 64 + lane) * 4]);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) r += *reinterpret_cast<const f32x4*>(&red[((w * 4 + wave) * 64 + lane) * 4]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stg(T.dW + (size_t)(k0 + 4 * q + i) * T.ldw + n0 + 16 * wave + c, r[i]);
+        if (tk == 0 && T.db && q == 0) {
+            const int j = 16 * wave + c;
+            T.db[n0 + j] = redb[0][j] + redb[1][j] + redb[2][j] + redb[3][j];
+        }
+    }
+}
 __global__ __launch_bounds__(FQL_THREADS) void fql_wgrad_kernel(const WgradTask* __restrict__ tasks, int ntasks) {
     __shared__ __attribute__((aligned(16))) float lds_w[FQL_WGRAD_LDS_FLOATS];
     wgrad_body(tasks[find_task(tasks, ntasks, blockIdx.x)], blockIdx.x, lds_w);
@@ -2189,7 +2545,7 @@ __global__ void fql_dataset_add_kernel(float* obs, float* act, float* rew, float
 #ifndef FQL_SIDE_VGPRS
 #define FQL_SIDE_VGPRS 168
 #endif
-template <bool BIG>   // BIG: the launch contains 64 x 64 tile tasks (batches >= 1024)
+template <bool BIG, bool SPLIT = false>   // BIG: the launch contains 64 x 64 tile tasks (batches >= 1024); SPLIT: precision = 2 (bf16 x 3)
 __device__ __forceinline__ void side_body(const GemmTask* __restrict__ gt, int ngt, const WgradTask* __restrict__ wt, int nwt, const LnBwdTask* __restrict__ lt,
                                           int nlt, int tile_w, int tile_l, const MiscTask* __restrict__ mt, int tile_m, int prio) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2198,10 +2554,11 @@ __device__ __forceinline__ void side_body(const GemmTask* __restrict__ gt, int n
     else if (prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (prio == 3) __builtin_amdgcn_s_setprio(3);
     if (b < tile_w) {
-        gemm_tile_dispatch<BIG>(gt[find_task(gt, ngt, b)], lds);
+        gemm_tile_dispatch<BIG, SPLIT>(gt[find_task(gt, ngt, b)], lds);
     } else if (b < tile_l) {
         const int bid = b - tile_w;
-        wgrad_body(wt[find_task(wt, nwt, bid)], bid, lds);
+        if (SPLIT) wgrad_split_body(wt[find_task(wt, nwt, bid)], bid, lds);
+        else wgrad_body(wt[find_task(wt, nwt, bid)], bid, lds);
     } else if (b < tile_m) {
         const int bid = b - tile_l;
         const LnBwdTask& T = lt[find_task(lt, nlt, bid)];
@@ -2225,6 +2582,14 @@ __global__ __launch_bounds__(FQL_THREADS, FQL_SIDE_WAVES) void fql_side_kernel(
     const MiscTask* __restrict__ mt, int tile_m, int prio, int tl) {
     tl_enter(tl);
     side_body<false>(gt, ngt, wt, nwt, lt, nlt, tile_w, tile_l, mt, tile_m, prio);
+    tl_exit(tl);
+}
+// precision = 2: same launch contract, split-bf16 tile and weight-gradient bodies (32-row tiles only)
+__global__ __launch_bounds__(FQL_THREADS, FQL_SIDE_WAVES) void fql_side_split_kernel(
+    const GemmTask* __restrict__ gt, int ngt, const WgradTask* __restrict__ wt, int nwt, const LnBwdTask* __restrict__ lt, int nlt, int tile_w, int tile_l,
+    const MiscTask* __restrict__ mt, int tile_m, int prio, int tl) {
+    tl_enter(tl);
+    side_body<false, true>(gt, ngt, wt, nwt, lt, nlt, tile_w, tile_l, mt, tile_m, prio);
     tl_exit(tl);
 }
 __global__ __launch_bounds__(FQL_THREADS, 2) void fql_side_big_kernel(

@@ -71,7 +71,10 @@ typedef struct fql_config {
     int32_t flow_steps;                      /* 10                                                 */
     int32_t normalize_q_loss;                /* False                                              */
     int32_t batch_size;                      /* 256: rows per update on this device (multiple of 16) */
-    int32_t precision;                       /* 0 = fp32 MFMA (exact fp32 fma chains)              */
+    int32_t precision;                       /* 0 = fp32 MFMA (exact fp32 fma chains; default).  2 = "bf16x3": every fp32 operand of the dense
+                                                contractions is split into hi + lo bf16 and a b = a_hi b_hi + a_hi b_lo + a_lo b_hi runs on the
+                                                bf16 matrix cores with fp32 accumulation (~2^-17 relative per product; parameters, activations,
+                                                gradients and the optimizer stay fp32).  1 (plain bf16) is rejected: it cannot hold the 1e-4 loss bound */
     int32_t encoder;                         /* 0 = state observations; 1 = impala_small, 2 = impala (utils/encoders.py:104,106; stacks 16/32/32, 1 or 2 blocks): obs_dim is
                                                 ignored, observations are uint8 [B, img_h, img_w, img_c] (agents/fql.py:196-202) */
     int32_t img_h, img_w, img_c;             /* image shape after frame stacking (e.g. 64, 64, 9); img_h, img_w multiples of 8 */
