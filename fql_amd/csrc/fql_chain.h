@@ -58,11 +58,41 @@ struct WfragTask {
     int K, N, ld;     // K multiple of 4
     int kvalid;       // rows [kvalid, K) are written as zeros (the rank-update block may run past the layer's padded input rows)
     int tile0;        // first workgroup of this task
+    int mode;         // 0: fp32 Wf[k/4][n][4].  precision = 2 (fql_chain_split_kernel): 1 = split 16x16x32 operands
+                      // dst[((k/32) N + n) 4 + q][hi 4 words | lo 4 words], lane (n, q) owns k = 32 j + 8 q .. + 7 (K multiple of 32);
+                      // 2 = split 16x16x16 operands dst[(k/4) N + n][hi 2 words | lo 2 words] (the 16-row rank-update block)
 };
 __global__ __launch_bounds__(FQL_THREADS) void fql_wfrag_kernel(const WfragTask* __restrict__ tasks, int ntasks, int tl) {
     tl_enter(tl);
     const WfragTask& T = tasks[find_task(tasks, ntasks, blockIdx.x)];
     const int e = (blockIdx.x - T.tile0) * FQL_THREADS + threadIdx.x;   // one (k4, n) per thread
+    if (T.mode == 1) {   // one (j, q, n) per thread: 8 k values -> 32 bytes
+        const int n = e % T.N, r = e / T.N;
+        const int q = r & 3, j = r >> 2;
+        if (j >= (T.K >> 5)) return;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int k = 32 * j + 8 * q + i; v[i] = (k < T.kvalid) ? ldg(T.src + (size_t)k * T.ld + n) : 0.f; }
+        u32x4 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { unsigned h, l; bsplit2(v[2 * i], v[2 * i + 1], h, l); hi[i] = h; lo[i] = l; }
+        unsigned* d = reinterpret_cast<unsigned*>(T.dst) + (((size_t)j * T.N + n) * 4 + q) * 8;
+        *(FQL_GAS u32x4*)d = hi;
+        *(FQL_GAS u32x4*)(d + 4) = lo;
+        return;
+    }
+    if (T.mode == 2) {
+        const int n = e % T.N, k4 = e / T.N;
+        if (k4 >= (T.K >> 2)) return;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (4 * k4 + i < T.kvalid) ? ldg(T.src + (size_t)(4 * k4 + i) * T.ld + n) : 0.f;
+        unsigned h0, l0, h1, l1;
+        bsplit2(v[0], v[1], h0, l0);
+        bsplit2(v[2], v[3], h1, l1);
+        *(FQL_GAS u32x4*)(reinterpret_cast<unsigned*>(T.dst) + ((size_t)k4 * T.N + n) * 4) = u32x4{h0, h1, l0, l1};
+        return;
+    }
     const int n = e % T.N, k4 = e / T.N;
     if (k4 >= (T.K >> 2)) return;
     f32x4 v;
@@ -227,5 +257,176 @@ __global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_
         for (int i = 0; i < nst; ++i) d[i] = stamp[i];
     }
 #endif
+}
+// ------------------------------------------------------------------------------------------------
+// precision = 2: the same three variants with split-bf16 operands (fql_kernels.h, top).  Weights arrive pre-split from
+// fql_wfrag_kernel (modes 1 / 2: one 16-byte hi and one 16-byte lo load per lane and 32-deep MFMA step, the bytes of the fp32
+// fragment copy); the 16 x H activation tile is split once by the thread that stages it into hi / lo planes [16][H/2 words] whose
+// 4-word slots are XOR-swizzled with the row (rows are a multiple of 64 words apart: unswizzled, every row would sit on the same
+// banks; with the swizzle both the b128 fragment reads and the b64 staging writes are conflict-free).  Per wave and K-quarter:
+// 3 x H/128 MFMAs of 16 cycles instead of H/16 of 32.
+// ------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 ldg4u(const unsigned* p) { return *(const FQL_GAS u32x4*)p; }
+__device__ __forceinline__ f32x4 mfma_bf16_k16(const u32x2& a, const u32x2& b, const f32x4& acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), acc, 0, 0, 0);
+}
+template <int H>
+__global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_split_kernel(const ChainArgs P) {
+    static_assert(H % 128 == 0 && H <= 1024, "hidden width must be a multiple of 128");
+    constexpr int RS = H / 2;         // words per row of an A plane
+    constexpr int NS = H / 128;       // 32-deep MFMA steps per K-quarter
+    constexpr int NA = H / 128;       // float4 loads per thread that cover the 16 x H A tile
+    constexpr int CT = H / 128;       // layer-0 column tiles per wave (variant A)
+    constexpr int NT = H / 32;        // column tiles = head partials per row tile
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned* ahi = reinterpret_cast<unsigned*>(lds);   // [16][RS]
+    unsigned* alo = ahi + 16 * RS;
+    float* red = reinterpret_cast<float*>(alo + 16 * RS);   // [4 K-quarters][2 column tiles][64 lanes] float4
+    float* ea = red + 4 * 2 * 64 * 4; // [16][32] actions of this step (variant A)
+    float* hs = ea + 512;             // [16][36] GELU tile feeding the head partial (variant C)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 15, q = lane >> 4;
+    const int nt = wave & 1, kp = wave >> 1;
+    const int tm = blockIdx.x / NT, tn = blockIdx.x - tm * NT;
+    const int row0 = tm * 16, n0 = tn * 32 + nt * 16;
+    const int variant = P.variant;
+    tl_enter(P.tl);
+    // ---- every load of the launch that does not depend on another workgroup's data of THIS launch goes out first
+    u32x4 bh[NS], bl[NS];
+    {
+        const unsigned* wb = reinterpret_cast<const unsigned*>(P.Wf) + (((size_t)(kp * NS) * H + n0 + c) * 4 + q) * 8;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { bh[s] = ldg4u(wb + (size_t)s * H * 32); bl[s] = ldg4u(wb + (size_t)s * H * 32 + 4); }
+    }
+    const float bias = ldg(P.bias + n0 + c);
+    u32x4 w4h, w4l;
+    if (variant == 2 && wave == 0) {
+        const unsigned* w4 = reinterpret_cast<const unsigned*>(P.W4f) + (((size_t)tn * P.ap + c) * 4 + q) * 8;
+        w4h = ldg4u(w4); w4l = ldg4u(w4 + 4);
+    }
+    if (variant == 0) {
+        // layer 0: C0 (loop invariant) + [a_s | t_s | 0] (16 x 16) times the 16 rows of W0 that start at the action block
+        f32x4 cacc[CT];
+        u32x4 wf[CT];   // hi 2 words | lo 2 words of k = 4q .. 4q + 3
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int ct = wave + 8 * t;
+            cacc[t] = ldg4(P.A + ((size_t)((row0 >> 2) + q) * H + 16 * ct + c) * 4);   // C layout: rows 4q + i, column c
+            wf[t] = ldg4u(reinterpret_cast<const unsigned*>(P.W0f) + ((size_t)q * H + 16 * ct + c) * 4);
+        }
+        {   // a_s = a_{s-1} + (sum of head partials + head bias) / flow_steps: two threads per element, fixed order
+            const int e = tid >> 1, half = tid & 1;
+            const int r = e >> 4, j = e & 15;
+            float a = 0.f;
+            if (j < P.ad) {
+                a = ldg(P.ea_in + (size_t)(row0 + r) * P.ea_ld + j);
+                if (P.evp_in) {
+                    float pv[NT / 2];
+                    const float* pp = P.evp_in + ((size_t)(half * (NT / 2)) * P.M + row0 + r) * P.ap + j;
+#pragma unroll
+                    for (int tp = 0; tp < NT / 2; ++tp) pv[tp] = ldg(pp + (size_t)tp * P.M * P.ap);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int tp = 0; tp < NT / 2; ++tp) sum += pv[tp];
+                    const float other = __shfl_xor(sum, 1);
+                    const float tot = half ? other + sum : sum + other;   // (partials 0..NT/2-1) + (NT/2..NT-1) on both lanes
+                    a += (tot + ldg(P.eb + j)) * P.inv_steps;
+                }
+                if (tn == 0 && half == 0 && P.ea_out) stg(P.ea_out + (size_t)(row0 + r) * P.ap + j, a);
+            } else if (j == P.ad) {
+                a = P.t_s;
+            }
+            if (half == 0) ea[r * 32 + j] = a;
+        }
+        __syncthreads();
+        {
+            const f32x4 af = *reinterpret_cast<const f32x4*>(&ea[c * 32 + 4 * q]);   // A'[row c][k = 4q + s]
+            u32x2 afh, afl;
+            bsplit4(af, afh, afl);
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const u32x2 wh = u32x2{wf[t][0], wf[t][1]}, wl = u32x2{wf[t][2], wf[t][3]};
+                cacc[t] = mfma_bf16_k16(afl, wh, cacc[t]);
+                cacc[t] = mfma_bf16_k16(afh, wl, cacc[t]);
+                cacc[t] = mfma_bf16_k16(afh, wh, cacc[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const int ct = wave + 8 * t;
+                // GELU(row 4q + i, k = 16 ct + c) into the planes: lanes c, c ^ 1 pair up, the even one stores the hi word, the odd one the lo word
+                const int slot = 2 * ct + (c >> 3), wo = (c & 7) >> 1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = gelu_f(cacc[t][i]);
+                    const float o = __shfl_xor(v, 1);
+                    unsigned h, l;
+                    bsplit2((c & 1) ? o : v, (c & 1) ? v : o, h, l);
+                    const int row = 4 * q + i;
+                    unsigned* d = ((c & 1) ? alo : ahi) + row * RS + 4 * (slot ^ row) + wo;
+                    *d = (c & 1) ? l : h;
+                }
+            }
+        }
+    } else {
+        f32x4 av[NA];
+        const float* Ag = P.A + (size_t)row0 * H;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) av[i] = ldg4(Ag + (size_t)(tid + i * FQL_CHAIN_THREADS) * 4);   // 16 rows of H floats are contiguous
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int f = tid + i * FQL_CHAIN_THREADS;
+            const int r = f / (H / 4), kk = f - r * (H / 4);
+            u32x2 hi, lo;
+            bsplit4(av[i], hi, lo);
+            const int w = r * RS + 4 * ((kk >> 1) ^ r) + 2 * (kk & 1);
+            *reinterpret_cast<u32x2*>(ahi + w) = hi;
+            *reinterpret_cast<u32x2*>(alo + w) = lo;
+        }
+    }
+    __syncthreads();
+    // ---- this wave's K-quarter: NS steps x 3 MFMAs on three accumulator chains
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int w = c * RS + 4 * ((4 * (kp * NS + s) + q) ^ c);
+        const u32x4 fah = *reinterpret_cast<const u32x4*>(ahi + w);
+        const u32x4 fal = *reinterpret_cast<const u32x4*>(alo + w);
+        acc = mfma_bf16(fah, bh[s], acc);
+        acc2 = mfma_bf16(fah, bl[s], acc2);
+        acc3 = mfma_bf16(fal, bh[s], acc3);
+    }
+    acc += acc2 + acc3;
+    *reinterpret_cast<f32x4*>(&red[((kp * 2 + nt) * 64 + lane) * 4]) = acc;
+    __syncthreads();
+    // ---- epilogue shared by the 8 waves: wave (nt, kp) finishes row 4q + kp, column n0 + c of its column tile
+    float v = bias;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) v += red[((p * 2 + nt) * 64 + lane) * 4 + kp];
+    v = gelu_f(v);
+    const int row = row0 + 4 * q + kp;
+    if (variant != 2) {
+        stg(P.C + (size_t)row * H + n0 + c, v);
+    } else {
+        hs[(4 * q + kp) * 36 + 16 * nt + c] = v;
+        __syncthreads();
+        if (wave == 0) {   // 16 x 32 GELU tile times this workgroup's 32 rows of the head kernel: one 32-deep step
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&hs[c * 36 + 8 * q]);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&hs[c * 36 + 8 * q + 4]);
+            u32x2 h0, l0, h1, l1;
+            bsplit4(a0, h0, l0);
+            bsplit4(a1, h1, l1);
+            const u32x4 fah = u32x4{h0[0], h0[1], h1[0], h1[1]}, fal = u32x4{l0[0], l0[1], l1[0], l1[1]};
+            f32x4 pa = {0.f, 0.f, 0.f, 0.f};
+            pa = mfma_bf16(fal, w4h, pa);
+            pa = mfma_bf16(fah, w4l, pa);
+            pa = mfma_bf16(fah, w4h, pa);
+            if (c < P.ap) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) stg(P.evp_out + ((size_t)tn * P.M + row0 + 4 * q + i) * P.ap + c, pa[i]);
+            }
+        }
+    }
+    tl_exit(P.tl);
 }
 #define FQL_CHAIN_LDS_BYTES(H) ((size_t)(16 * ((H) + 4) + 4 * 2 * 64 * 4 + 512 + 16 * 36) * sizeof(float))

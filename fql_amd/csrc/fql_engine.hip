@@ -464,17 +464,18 @@ struct fql_engine {
         const int od = cfg.obs_dim, ap = pad16(cfg.act_dim);
         std::vector<WfragTask> tasks;
         int tile = 0;
-        auto add = [&](const float* src, int K, int N, int ld, int kvalid) {
+        const bool split = cfg.precision == 2;   // fql_chain_split_kernel reads pre-split bf16 hi / lo operands (same bytes)
+        auto add = [&](const float* src, int K, int N, int ld, int kvalid, int split_mode) {
             float* dst = dalloc(chain_allocs, (size_t)K * N);
-            tasks.push_back(WfragTask{src, dst, K, N, ld, kvalid, tile});
+            tasks.push_back(WfragTask{src, dst, K, N, ld, kvalid, tile, split ? split_mode : 0});
             tile += ((K / 4) * N + FQL_THREADS - 1) / FQL_THREADS;
             return dst;
         };
         wf_bc.clear();
-        for (int l = 1; l < nh; ++l) wf_bc.push_back(add(P + n.layers[l].w, H, H, H, H));
+        for (int l = 1; l < nh; ++l) wf_bc.push_back(add(P + n.layers[l].w, H, H, H, H, 1));
         const Layer& l0 = n.layers[0];
-        wf_w0 = add(P + l0.w + (size_t)od * l0.out_p, 16, H, l0.out_p, std::min(16, l0.in_p - od));   // rows of (action block, t, padding)
-        wf_w4 = add(P + n.layers[nh].w, H, ap, ap, H);
+        wf_w0 = add(P + l0.w + (size_t)od * l0.out_p, 16, H, l0.out_p, std::min(16, l0.in_p - od), 2);   // rows of (action block, t, padding)
+        wf_w4 = add(P + n.layers[nh].w, H, ap, ap, H, 1);
         wfrag_n = (int)tasks.size(); wfrag_grid = tile;
         d_wfrag = (WfragTask*)dalloc(chain_allocs, tasks.size() * sizeof(WfragTask) / sizeof(float) + 4);
         HIP_CHECK(hipMemcpy(d_wfrag, tasks.data(), tasks.size() * sizeof(WfragTask), hipMemcpyHostToDevice));
@@ -1770,7 +1771,11 @@ struct fql_engine {
             }
             case OP_CHAIN: {
                 ChainArgs ca = L.op.chain; ca.tl = tl;
-                if (cfg.actor_hidden[0] == 512) FQL_LAUNCH((fql_chain_kernel<512>), dim3((L.op.chain.M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, ca);
+                if (cfg.precision == 2) {
+                    if (cfg.actor_hidden[0] == 512) FQL_LAUNCH((fql_chain_split_kernel<512>), dim3((L.op.chain.M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, ca);
+                    else FQL_LAUNCH((fql_chain_split_kernel<256>), dim3((L.op.chain.M / 16) * 8), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(256), s, ca);
+                }
+                else if (cfg.actor_hidden[0] == 512) FQL_LAUNCH((fql_chain_kernel<512>), dim3((L.op.chain.M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, ca);
                 else FQL_LAUNCH((fql_chain_kernel<256>), dim3((L.op.chain.M / 16) * 8), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(256), s, ca);
                 break;
             }

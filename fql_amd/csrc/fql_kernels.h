@@ -35,10 +35,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ unsigned cvt_pk_bf16(float x0, float x1) {   // {bf16(x0) in bits 0-15, bf16(x1) in bits 16-31}
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x0), "v"(x1));
-    return r;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// {bf16(x0) in bits 0-15, bf16(x1) in bits 16-31}: one v_cvt_pk_bf16_f32.  Through the compiler's own conversion, NOT inline
+// assembly: the packed subtraction in front of the second conversion (v_pk_add_f32) needs a wait state before its result is read,
+// which the hazard recognizer only inserts for instructions it can see (an inline-asm conversion read garbage now and then).
+__device__ __forceinline__ unsigned cvt_pk_bf16(float x0, float x1) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
 }
 __device__ __forceinline__ void bsplit2(float x0, float x1, unsigned& hi, unsigned& lo) {
     hi = cvt_pk_bf16(x0, x1);
