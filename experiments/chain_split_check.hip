@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -23,11 +24,44 @@ static double maxdiff(const std::vector<float>& a, const std::vector<float>& b, 
     *ref = r; return m;
 }
 
+// host bf16 (round to nearest even) split of an [M][H] tensor into the hi / lo word planes the split chain passes between launches
+static unsigned bf16_rne(float x) { unsigned u; memcpy(&u, &x, 4); return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16; }
+static float bf16_f(unsigned b) { unsigned u = b << 16; float f; memcpy(&f, &u, 4); return f; }
+static std::vector<unsigned> split_planes(const std::vector<float>& a, int M, int H) {
+    std::vector<unsigned> w((size_t)M * H);
+    for (int m = 0; m < M; ++m)
+        for (int k = 0; k < H; k += 2) {
+            unsigned h[2], l[2];
+            for (int e = 0; e < 2; ++e) { const float x = a[(size_t)m * H + k + e]; h[e] = bf16_rne(x); l[e] = bf16_rne(x - bf16_f(h[e])); }
+            w[(size_t)m * (H / 2) + k / 2] = h[0] | (h[1] << 16);
+            w[(size_t)M * (H / 2) + (size_t)m * (H / 2) + k / 2] = l[0] | (l[1] << 16);
+        }
+    return w;
+}
+static std::vector<float> join_planes(const std::vector<float>& wf, int M, int H) {
+    std::vector<float> a((size_t)M * H);
+    const unsigned* w = reinterpret_cast<const unsigned*>(wf.data());
+    for (int m = 0; m < M; ++m)
+        for (int k = 0; k < H; ++k) {
+            const unsigned hw = w[(size_t)m * (H / 2) + k / 2], lw = w[(size_t)M * (H / 2) + (size_t)m * (H / 2) + k / 2];
+            a[(size_t)m * H + k] = bf16_f((k & 1) ? hw >> 16 : hw & 0xFFFFu) + bf16_f((k & 1) ? lw >> 16 : lw & 0xFFFFu);
+        }
+    return a;
+}
+
 int main() {
     const int M = 256, H = 512, ap = 16, ad = 8, od = 29;
     hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     float* A = dev((size_t)M * H, 1, 1.0f);          // activations in
-    float* C0 = dev((size_t)M * H, 2, 1.0f);         // loop-invariant layer-0 part, fragment-major
+    float* As;                                        // the same, as hi / lo planes
+    { std::vector<unsigned> w = split_planes(host(A, (size_t)M * H), M, H); CK(hipMalloc(&As, (size_t)M * H * 4)); CK(hipMemcpy(As, w.data(), (size_t)M * H * 4, hipMemcpyHostToDevice)); }
+    float* C0r = dev((size_t)M * H, 2, 1.0f);        // loop-invariant layer-0 part, row-major (what the split kernel reads)
+    float* C0;                                        // the same in accumulator-fragment-major layout [M/4][H][4] (fp32 kernel)
+    {
+        std::vector<float> r = host(C0r, (size_t)M * H), f((size_t)M * H);
+        for (int m = 0; m < M; ++m) for (int n = 0; n < H; ++n) f[((size_t)(m / 4) * H + n) * 4 + (m & 3)] = r[(size_t)m * H + n];
+        CK(hipMalloc(&C0, (size_t)M * H * 4)); CK(hipMemcpy(C0, f.data(), (size_t)M * H * 4, hipMemcpyHostToDevice));
+    }
     float* W = dev((size_t)H * H, 3, 0.08f);
     float* W0 = dev((size_t)48 * H, 4, 0.2f);        // layer-0 kernel rows (obs | act | t | pad), ld = H
     float* W4 = dev((size_t)H * ap, 5, 0.1f);
@@ -57,7 +91,7 @@ int main() {
         for (int v = 0; v < 2; ++v) {
             CK(hipMemset(Cout[v], 0, (size_t)M * H * 4)); CK(hipMemset(ea_out[v], 0, (size_t)M * ap * 4)); CK(hipMemset(evp_out[v], 0, (size_t)(H / 32) * M * ap * 4));
             ChainArgs a{};
-            a.A = variant == 0 ? C0 : A; a.Wf = Wf[v]; a.bias = bias; a.C = Cout[v];
+            a.A = variant == 0 ? (v ? C0r : C0) : (v ? As : A); a.Wf = Wf[v]; a.bias = bias; a.C = Cout[v];
             a.ea_in = ea_in; a.ea_out = ea_out[v]; a.W0f = W0f[v]; a.evp_in = evp_in; a.eb = eb;
             a.W4f = W4f[v]; a.evp_out = evp_out[v];
             a.M = M; a.ad = ad; a.ap = ap; a.ea_ld = 48; a.inv_steps = 0.1f; a.t_s = 0.3f; a.variant = variant; a.tl = -1; a.prio = 0; a.stamps = nullptr;
@@ -82,7 +116,7 @@ int main() {
             printf("variant %c %s: %.2f us per launch\n", "ABC"[variant], v ? "split" : "fp32 ", us);
         }
         double r;
-        if (variant != 2) { const double d = maxdiff(host(Cout[0], (size_t)M * H), host(Cout[1], (size_t)M * H), &r); printf("  C      max|fp32 - split| = %.3e (max|fp32| %.3f)\n", d, r); }
+        if (variant != 2) { const double d = maxdiff(host(Cout[0], (size_t)M * H), join_planes(host(Cout[1], (size_t)M * H), M, H), &r); printf("  C      max|fp32 - split| = %.3e (max|fp32| %.3f)\n", d, r); }
         if (variant == 0) { const double d = maxdiff(host(ea_out[0], (size_t)M * ap), host(ea_out[1], (size_t)M * ap), &r); printf("  ea_out max diff = %.3e (max %.3f)\n", d, r); }
         if (variant == 2) { const double d = maxdiff(host(evp_out[0], (size_t)(H / 32) * M * ap), host(evp_out[1], (size_t)(H / 32) * M * ap), &r); printf("  evp    max diff = %.3e (max %.3f)\n", d, r); }
     }

@@ -59,7 +59,8 @@ struct WfragTask {
     int kvalid;       // rows [kvalid, K) are written as zeros (the rank-update block may run past the layer's padded input rows)
     int tile0;        // first workgroup of this task
     int mode;         // 0: fp32 Wf[k/4][n][4].  precision = 2 (fql_chain_split_kernel): 1 = split 16x16x32 operands
-                      // dst[((k/32) N + n) 4 + q][hi 4 words | lo 4 words], lane (n, q) owns k = 32 j + 8 q .. + 7 (K multiple of 32);
+                      // dst[k/32][hi, lo][n][q][4 words], lane (n, q) owns k = 32 j + 8 q .. + 7 (K multiple of 32; a wave's 16-byte
+                      // loads of one plane are 1 KB contiguous);
                       // 2 = split 16x16x16 operands dst[(k/4) N + n][hi 2 words | lo 2 words] (the 16-row rank-update block)
 };
 __global__ __launch_bounds__(FQL_THREADS) void fql_wfrag_kernel(const WfragTask* __restrict__ tasks, int ntasks, int tl) {
@@ -76,9 +77,9 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_wfrag_kernel(const WfragTask*
         u32x4 hi, lo;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { unsigned h, l; bsplit2(v[2 * i], v[2 * i + 1], h, l); hi[i] = h; lo[i] = l; }
-        unsigned* d = reinterpret_cast<unsigned*>(T.dst) + (((size_t)j * T.N + n) * 4 + q) * 8;
+        unsigned* d = reinterpret_cast<unsigned*>(T.dst) + (((size_t)(2 * j) * T.N + n) * 4 + q) * 4;
         *(FQL_GAS u32x4*)d = hi;
-        *(FQL_GAS u32x4*)(d + 4) = lo;
+        *(FQL_GAS u32x4*)(d + (size_t)T.N * 16) = lo;
         return;
     }
     if (T.mode == 2) {
@@ -271,6 +272,14 @@ __device__ __forceinline__ u32x4 ldg4u(const unsigned* p) { return *(const FQL_G
 __device__ __forceinline__ f32x4 mfma_bf16_k16(const u32x2& a, const u32x2& b, const f32x4& acc) {
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), acc, 0, 0, 0);
 }
+// value of the lane whose column index differs in bit 0 (DPP quad_perm [1, 0, 3, 2]: no LDS crossbar round trip)
+__device__ __forceinline__ float lane_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+// Activations BETWEEN the launches of the split chain travel pre-split: a [M][H] tensor is a hi plane [M][H/2 words] followed by a
+// lo plane of the same shape (the bytes of the fp32 tensor; the buffers are private to the chain).  The producer's epilogue splits
+// each value once (lanes c, c ^ 1 pair up: the even one stores the hi word, the odd one the lo word); the consumer's staging is
+// 16-byte copies into the swizzled LDS planes, no arithmetic.
 template <int H>
 __global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_split_kernel(const ChainArgs P) {
     static_assert(H % 128 == 0 && H <= 1024, "hidden width must be a multiple of 128");
@@ -295,15 +304,15 @@ __global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_
     // ---- every load of the launch that does not depend on another workgroup's data of THIS launch goes out first
     u32x4 bh[NS], bl[NS];
     {
-        const unsigned* wb = reinterpret_cast<const unsigned*>(P.Wf) + (((size_t)(kp * NS) * H + n0 + c) * 4 + q) * 8;
+        const unsigned* wb = reinterpret_cast<const unsigned*>(P.Wf) + (((size_t)(2 * kp * NS) * H + n0 + c) * 4 + q) * 4;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) { bh[s] = ldg4u(wb + (size_t)s * H * 32); bl[s] = ldg4u(wb + (size_t)s * H * 32 + 4); }
+        for (int s = 0; s < NS; ++s) { bh[s] = ldg4u(wb + (size_t)s * H * 32); bl[s] = ldg4u(wb + (size_t)s * H * 32 + H * 16); }
     }
     const float bias = ldg(P.bias + n0 + c);
     u32x4 w4h, w4l;
     if (variant == 2 && wave == 0) {
-        const unsigned* w4 = reinterpret_cast<const unsigned*>(P.W4f) + (((size_t)tn * P.ap + c) * 4 + q) * 8;
-        w4h = ldg4u(w4); w4l = ldg4u(w4 + 4);
+        const unsigned* w4 = reinterpret_cast<const unsigned*>(P.W4f) + (((size_t)(2 * tn) * P.ap + c) * 4 + q) * 4;
+        w4h = ldg4u(w4); w4l = ldg4u(w4 + P.ap * 16);
     }
     if (variant == 0) {
         // layer 0: C0 (loop invariant) + [a_s | t_s | 0] (16 x 16) times the 16 rows of W0 that start at the action block
@@ -312,7 +321,7 @@ __global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
             const int ct = wave + 8 * t;
-            cacc[t] = ldg4(P.A + ((size_t)((row0 >> 2) + q) * H + 16 * ct + c) * 4);   // C layout: rows 4q + i, column c
+            cacc[t] = ldg4(P.A + (size_t)(row0 + c) * H + 16 * ct + 4 * q);   // C0 row-major: row c, columns 16 ct + 4q .. + 3 (layer 0 runs transposed)
             wf[t] = ldg4u(reinterpret_cast<const unsigned*>(P.W0f) + ((size_t)q * H + 16 * ct + c) * 4);
         }
         {   // a_s = a_{s-1} + (sum of head partials + head bias) / flow_steps: two threads per element, fixed order
@@ -341,47 +350,47 @@ __global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_
         }
         __syncthreads();
         {
+            // layer 0 TRANSPOSED: D[n][row] = sum_k W0[k][n] A'[row][k] - the weight fragment is the A operand, the action fragment the B
+            // operand (the same registers, swapped) - so a lane ends up with 4 CONSECUTIVE columns n = 16 ct + 4q + i of row c: its GELU
+            // values are 2 hi + 2 lo words, one 8-byte LDS store per plane, no lane exchange
             const f32x4 af = *reinterpret_cast<const f32x4*>(&ea[c * 32 + 4 * q]);   // A'[row c][k = 4q + s]
             u32x2 afh, afl;
             bsplit4(af, afh, afl);
 #pragma unroll
             for (int t = 0; t < CT; ++t) {
                 const u32x2 wh = u32x2{wf[t][0], wf[t][1]}, wl = u32x2{wf[t][2], wf[t][3]};
-                cacc[t] = mfma_bf16_k16(afl, wh, cacc[t]);
-                cacc[t] = mfma_bf16_k16(afh, wl, cacc[t]);
-                cacc[t] = mfma_bf16_k16(afh, wh, cacc[t]);
+                cacc[t] = mfma_bf16_k16(wl, afh, cacc[t]);
+                cacc[t] = mfma_bf16_k16(wh, afl, cacc[t]);
+                cacc[t] = mfma_bf16_k16(wh, afh, cacc[t]);
             }
 #pragma unroll
             for (int t = 0; t < CT; ++t) {
                 const int ct = wave + 8 * t;
-                // GELU(row 4q + i, k = 16 ct + c) into the planes: lanes c, c ^ 1 pair up, the even one stores the hi word, the odd one the lo word
-                const int slot = 2 * ct + (c >> 3), wo = (c & 7) >> 1;
+                f32x4 g;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float v = gelu_f(cacc[t][i]);
-                    const float o = __shfl_xor(v, 1);
-                    unsigned h, l;
-                    bsplit2((c & 1) ? o : v, (c & 1) ? v : o, h, l);
-                    const int row = 4 * q + i;
-                    unsigned* d = ((c & 1) ? alo : ahi) + row * RS + 4 * (slot ^ row) + wo;
-                    *d = (c & 1) ? l : h;
-                }
+                for (int i = 0; i < 4; ++i) g[i] = gelu_f(cacc[t][i]);
+                u32x2 hi, lo;
+                bsplit4(g, hi, lo);
+                const int w = c * RS + 4 * ((2 * ct + (q >> 1)) ^ c) + 2 * (q & 1);
+                *reinterpret_cast<u32x2*>(ahi + w) = hi;
+                *reinterpret_cast<u32x2*>(alo + w) = lo;
             }
         }
     } else {
-        f32x4 av[NA];
-        const float* Ag = P.A + (size_t)row0 * H;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) av[i] = ldg4(Ag + (size_t)(tid + i * FQL_CHAIN_THREADS) * 4);   // 16 rows of H floats are contiguous
+        // 16 rows x RS words of each plane are contiguous: 16-byte pieces, NA / 2 per thread and plane
+        u32x4 av[NA];
+        const unsigned* Ah = reinterpret_cast<const unsigned*>(P.A) + (size_t)row0 * RS;
+        const unsigned* Al = Ah + (size_t)P.M * RS;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int f = tid + i * FQL_CHAIN_THREADS;
-            const int r = f / (H / 4), kk = f - r * (H / 4);
-            u32x2 hi, lo;
-            bsplit4(av[i], hi, lo);
-            const int w = r * RS + 4 * ((kk >> 1) ^ r) + 2 * (kk & 1);
-            *reinterpret_cast<u32x2*>(ahi + w) = hi;
-            *reinterpret_cast<u32x2*>(alo + w) = lo;
+            const int pc = (tid + i * FQL_CHAIN_THREADS) & (4 * RS - 1);   // piece inside the plane: row pc / (RS / 4), slot pc % (RS / 4)
+            av[i] = ldg4u((i < NA / 2 ? Ah : Al) + (size_t)pc * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int pc = (tid + i * FQL_CHAIN_THREADS) & (4 * RS - 1);
+            const int r = pc / (RS / 4), sl = pc - r * (RS / 4);
+            *reinterpret_cast<u32x4*>((i < NA / 2 ? ahi : alo) + r * RS + 4 * (sl ^ r)) = av[i];
         }
     }
     __syncthreads();
@@ -406,7 +415,11 @@ __global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_
     v = gelu_f(v);
     const int row = row0 + 4 * q + kp;
     if (variant != 2) {
-        stg(P.C + (size_t)row * H + n0 + c, v);
+        const float o = lane_xor1(v);
+        unsigned h, l;
+        bsplit2((c & 1) ? o : v, (c & 1) ? v : o, h, l);
+        unsigned* Cw = reinterpret_cast<unsigned*>(P.C) + ((c & 1) ? (size_t)P.M * RS : 0) + (size_t)row * RS + ((n0 + c) >> 1);
+        *(FQL_GAS unsigned*)Cw = (c & 1) ? l : h;
     } else {
         hs[(4 * q + kp) * 36 + 16 * nt + c] = v;
         __syncthreads();
