@@ -21,6 +21,9 @@ Prints ONE JSON line on rank 0.  Besides the contract fields:
   whole_update  the same accounting over the whole update on the fenced wall clock
   kernels       every kernel family of the update: launches, average us, share of the serialised device time
   cpu_baseline  the torch-CPU restatement of the reference update (oracle/, kind "port") on this host's cores, bounded sample
+  precision_bf16x3  (N = 1, state workload, headline run in fp32) the same workload, steps and warm-up on a second agent created with
+                precision='bf16x3' (fql_config.precision = 2: split-bf16 products on the bf16 matrix cores, fp32 accumulation): its rate,
+                its dominant kernel against the bf16 peak / 3, and its loss delta against the fp64 oracle.  Never `value`.
 """
 import argparse
 import ctypes as C
@@ -35,6 +38,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (matrix), v_mfma_f32_16x16x4_f32
+BF16_MATRIX_PEAK_TFLOPS = 2516.6  # dense bf16 matrix peak; a bf16x3 product is three bf16 MFMAs: peak / 3 = 838.9 algorithmic TFLOP/s
 OP_NAMES = ['fql_gemm16_kernel', 'fql_side_kernel', 'fql_wgrad_kernel', 'fql_lnbwd_kernel', 'fql_prep_kernel', 'fql_post_onestep_kernel',
             'fql_euler_finish_kernel', 'fql_euler_persistent_kernel', 'fql_loss_critic_kernel', 'fql_loss_q_kernel', 'fql_loss_bc_kernel',
             'fql_loss_actor_kernel', 'fql_conv_wprep_kernel', 'fql_conv3x3_kernel', 'fql_conv3x3_u8_kernel', 'fql_maxpool_kernel',
@@ -89,8 +93,12 @@ def cpu_baseline(cfg, od, ad, B, budget_s=18.0, img=None):
             'threads_scan': {str(t): round(v[0], 3) for t, v in scan.items()}, 'host_cores': int(cores)}
 
 
-def profile_kernels(agent, B, reps):
+def profile_kernels(agent, B, reps, split=False):
     """Per-launch device times (HIP events on the engine's stream) of `reps` updates -> per kernel family statistics."""
+    names = list(OP_NAMES)
+    if split:   # precision = 2 launches the split bodies for the side lanes and the Euler chain (the tail's input-gradient chain launches stay fp32)
+        names[OP_NAMES.index('fql_side_kernel')] = 'fql_side_split_kernel'
+        names[OP_NAMES.index('fql_chain_kernel')] = 'fql_chain_split_kernel (+ 3 fp32 fql_chain_kernel dgrad launches)'
     from fql_amd import _cabi
     lib = _cabi.load()
     f = lib.fql_profile_update
@@ -111,7 +119,7 @@ def profile_kernels(agent, B, reps):
         # quantity `rocprofv3 --kernel-trace --stats` averages - nothing to calibrate
         gap = 0.0
         for i in range(n):
-            d = fam.setdefault(OP_NAMES[typ[i]], {'launches': 0, 'us': 0.0, 'macs': 0.0, 'min_us': 1e9, 'max_us': 0.0, 'raw': 0.0})
+            d = fam.setdefault(names[typ[i]], {'launches': 0, 'us': 0.0, 'macs': 0.0, 'min_us': 1e9, 'max_us': 0.0, 'raw': 0.0})
             t = max(0.5, us[i] - gap)
             d['launches'] += 1; d['us'] += t; d['macs'] += macs[i]; d['raw'] += us[i]
             d['min_us'] = min(d['min_us'], t); d['max_us'] = max(d['max_us'], t)
@@ -122,6 +130,69 @@ def profile_kernels(agent, B, reps):
                   'share': d['us'] / tot, 'flop_per_launch': 2.0 * d['macs'] / d['launches'], 'min_us': d['min_us'], 'max_us': d['max_us'],
                   'event_interval_us': d['raw'] / d['launches'], 'null_interval_us': float(np.median(nulls))}
     return out
+
+
+def bench_bf16x3(args, cfg, ds, od, ad, B, torch):
+    """Second agent, precision='bf16x3', same workload / steps / warm-up / fences as the headline; never the headline `value`."""
+    import fql_amd
+    c2 = fql_amd.get_config()
+    c2.update({k: v for k, v in dict(cfg).items() if k not in ('ob_dims', 'action_dim')})
+    c2['precision'] = 'bf16x3'
+    agent = fql_amd.FQLAgent.create(0, ds['observations'][:1], ds['actions'][:1], c2)
+    agent.upload_dataset(ds)
+    for _ in range(args.warmup):
+        agent.update_from_dataset(B)
+    torch.cuda.synchronize(); agent.read_info()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        agent.update_from_dataset(B)
+    agent.read_info(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = agent.stats()
+    rate = args.steps / dt
+    flop = 2.0 * st['macs_per_update']
+    whole = flop * rate / 1e12
+    peak = BF16_MATRIX_PEAK_TFLOPS / 3.0
+    res = {'value': round(rate, 2), 'unit': 'grad-steps/s', 'ms_per_step': round(dt * 1e3 / args.steps, 5), 'steps': args.steps, 'warmup': args.warmup,
+           'dtype': 'bf16x3 (fp32 operands split into hi + lo bf16, a b = a_hi b_hi + a_hi b_lo + a_lo b_hi on v_mfma_f32_16x16x32_bf16, fp32 accumulate; '
+                    'parameters, activations, gradients, Adam in fp32)',
+           'whole_update': {'achieved_tflops': round(whole, 3), 'frac_of_bf16_matrix_peak_over_3': round(whole / peak, 4),
+                            'kernel_launches_per_update': st['launches_per_update']}}
+    fams = profile_kernels(agent, B, reps=20, split=True)
+    if fams:
+        mm = {k: v for k, v in fams.items() if v['flop_per_launch'] > 0}
+        dom = max(mm, key=lambda k: mm[k]['us_per_update'])
+        d = mm[dom]
+        ach = d['flop_per_launch'] / (d['avg_us'] * 1e-6) / 1e12
+        res['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                           'traffic': None, 'kernel': dom, 'flop_per_launch': round(d['flop_per_launch']), 'avg_launch_us': round(d['avg_us'], 3),
+                           'launches_per_update': round(d['launches_per_update'], 2),
+                           'peak_note': 'dense bf16 matrix peak 2516.6 TFLOP/s / 3 MFMAs per product; the kernel is latency-bound, not MFMA-bound'}
+        pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_summary_bf16x3.json')
+        if os.path.exists(pmc):
+            try:
+                pj = json.load(open(pmc))
+                k = pj.get('kernels', {}).get('fql_side_split_kernel')
+                if k:
+                    res['roofline']['traffic'] = k.get('hbm_bytes_per_launch')
+                    res['roofline']['mfma_util'] = k.get('mfma_util')
+                    res['roofline']['traffic_source'] = pj.get('source')
+            except Exception:
+                pass
+        res['kernels'] = {k: {'launches': round(v['launches_per_update'], 2), 'avg_us': round(v['avg_us'], 2), 'share': round(v['share'], 4)}
+                          for k, v in sorted(fams.items(), key=lambda kv: -kv[1]['us_per_update'])}
+    if not args.no_cpu_baseline:
+        from oracle import fql_oracle as O   # checker only
+        pb = O.sample_batch(ds, np.random.default_rng(3).integers(0, args.rows, size=B))
+        pn = O.make_noise(B, ad, 4)
+        ref = O.OracleFQL(agent.get_params(), {k: v for k, v in dict(c2).items() if k != 'rng'}, od, ad, np.float64)
+        lg, ig = agent.total_loss(pb, None, noise=pn)
+        lr, ir = ref.total_loss(pb, pn)
+        res['loss_delta'] = {'total_loss_gpu': round(float(lg), 6), 'total_loss_oracle': round(float(lr), 6), 'abs_delta': float(abs(lg - lr)),
+                             'max_abs_delta_info': float(max(abs(ig[k] - ir[k]) for k in ir)),
+                             'per_info': {k: float(ig[k] - ir[k]) for k in ir}}
+    agent.close()
+    return res
 
 
 def main():
@@ -167,6 +238,7 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     od, ad, B = args.obs_dim, args.act_dim, args.batch
+    peak_tf = FP32_MATRIX_PEAK_TFLOPS if args.precision == 'fp32' or args.workload == 'visual' else BF16_MATRIX_PEAK_TFLOPS / 3.0
     cfg = fql_amd.get_config()
     visual = args.workload == 'visual'
     seed = 0    # the same seed on every rank: DataParallelFQL mixes the rank into the device RNG stream
@@ -232,24 +304,24 @@ def main():
         out = {
             'metric': 'FQL gradient-steps/s (batch=256)', 'value': round(steps_per_s * world, 2), 'unit': 'grad-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt * 1e3 / args.steps, 5),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' or visual else 'bf16x3', 'data': 'synthetic',
             'config': {'workload': work, 'parallelism': f'dp{world}', 'samples_per_s': round(steps_per_s * world * B, 1)},
             'whole_update': {'flop': flop_per_step, 'wall_us': round(step_us_wall, 3), 'achieved_tflops': round(whole, 3),
-                             'frac_of_fp32_matrix_peak': round(whole / FP32_MATRIX_PEAK_TFLOPS, 4),
+                             ('frac_of_fp32_matrix_peak' if peak_tf == FP32_MATRIX_PEAK_TFLOPS else 'frac_of_bf16_matrix_peak_over_3'): round(whole / peak_tf, 4),
                              'kernel_launches_per_update': st['launches_per_update']},
             'last_info': {k: round(v, 5) for k, v in info.items()},
         }
-        roof = {'bound': 'mfma', 'achieved': round(whole, 3), 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(whole / FP32_MATRIX_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': 'whole update (per-kernel pass skipped)'}
+        roof = {'bound': 'mfma', 'achieved': round(whole, 3), 'peak': peak_tf, 'unit': 'TFLOP/s',
+                'frac': round(whole / peak_tf, 4), 'traffic': None, 'kernel': 'whole update (per-kernel pass skipped)'}
         if world == 1 and not args.no_extras:
-            fams = profile_kernels(agent, B, reps=20)
+            fams = profile_kernels(agent, B, reps=20, split=(args.precision == 'bf16x3' and not visual))
             if fams:
                 mm = {k: v for k, v in fams.items() if v['flop_per_launch'] > 0}
                 dom = max(mm, key=lambda k: mm[k]['us_per_update'])
                 d = mm[dom]
                 ach = d['flop_per_launch'] / (d['avg_us'] * 1e-6) / 1e12
-                roof = {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': dom,
+                roof = {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': peak_tf, 'unit': 'TFLOP/s',
+                        'frac': round(ach / peak_tf, 4), 'traffic': None, 'kernel': dom,
                         'flop_per_launch': round(d['flop_per_launch']), 'avg_launch_us': round(d['avg_us'], 3),
                         'launches_per_update': round(d['launches_per_update'], 2),
                         'measured': 'start / stop HIP events attached to every dispatch (hipExtLaunchKernelGGL) of 20 updates issued in program '
@@ -285,6 +357,8 @@ def main():
                 out['host_batch_update'] = {'value': round(nh / (time.perf_counter() - t1), 1), 'unit': 'grad-steps/s',
                                             'note': 'agent.update(numpy batch) with lazy info, ~70 KB staged H2D per call (PCIe-inclusive; never `value`)'}
         out['roofline'] = roof
+        if world == 1 and not args.no_extras and not visual and args.precision == 'fp32' and not force_dp:
+            out['precision_bf16x3'] = bench_bf16x3(args, cfg, ds, od, ad, B, torch)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, od, ad, B, img=(64, 64, 9) if visual else None)
             if not visual:

@@ -11,6 +11,11 @@
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
+static void launch_chain(hipStream_t s, const ChainArgs& a) {
+    if (a.variant == 0) hipLaunchKernelGGL((fql_chain_kernel<512, 0>), dim3(256), dim3(512), FQL_CHAIN_LDS_BYTES(512), s, a);
+    else if (a.variant == 1) hipLaunchKernelGGL((fql_chain_kernel<512, 1>), dim3(256), dim3(512), FQL_CHAIN_LDS_BYTES(512), s, a);
+    else hipLaunchKernelGGL((fql_chain_kernel<512, 2>), dim3(256), dim3(512), FQL_CHAIN_LDS_BYTES(512), s, a);
+}
 static double time_graph(hipStream_t s, hipGraphExec_t ge, int launches) {
     for (int i = 0; i < 20; ++i) CK(hipGraphLaunch(ge, s));
     CK(hipStreamSynchronize(s));
@@ -40,7 +45,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(W0f, hw.data(), (size_t)16 * H * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(W4f, hw.data(), (size_t)H * ap * 4, hipMemcpyHostToDevice));
     CK(hipMemset(b, 0, 4096 * 4)); CK(hipMemset(evp, 0, (size_t)(H / 32) * M * ap * 4)); CK(hipMemset(ea0, 0, (size_t)M * 64 * 4)); CK(hipMemset(ea1, 0, (size_t)M * ap * 4));
     unsigned long long* stamps; CK(hipMalloc(&stamps, 8 * 4096 * 8)); CK(hipMemset(stamps, 0, 8 * 4096 * 8));
-    CK(hipFuncSetAttribute((const void*)fql_chain_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FQL_CHAIN_LDS_BYTES(512)));
+    CK(hipFuncSetAttribute((const void*)fql_chain_kernel<512, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FQL_CHAIN_LDS_BYTES(512)));
 
     // ---- old: gemm16 kernel, 8 tasks ping-pong with different weights
     {
@@ -97,7 +102,7 @@ int main(int argc, char** argv) {
     {
         hipGraph_t g; hipGraphExec_t ge;
         CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        for (int i = 0; i < 96; ++i) { ChainArgs a = base(i); hipLaunchKernelGGL((fql_chain_kernel<512>), dim3(256), dim3(512), FQL_CHAIN_LDS_BYTES(512), s, a); }
+        for (int i = 0; i < 96; ++i) { ChainArgs a = base(i); launch_chain(s, a); }
         CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         printf("new chain kernel, variant B (512 threads, fragment-major W, kernarg task): %.2f us per launch\n", time_graph(s, ge, 96));
         report_stamps("B");
@@ -113,7 +118,7 @@ int main(int argc, char** argv) {
             if (v == 0) { a.A = C0f; a.W0f = W0f; a.ea_in = ea0; a.ea_ld = 64; a.ea_out = ea1; a.evp_in = evp; a.eb = b; a.C = A0; }
             if (v == 1) { a.A = A0; a.C = A1; }
             if (v == 2) { a.A = A1; a.C = nullptr; a.W4f = W4f; a.evp_out = evp; }
-            hipLaunchKernelGGL((fql_chain_kernel<512>), dim3(256), dim3(512), FQL_CHAIN_LDS_BYTES(512), s, a);
+            launch_chain(s, a);
         }
         CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         const double us = time_graph(s, ge, 96);
@@ -127,7 +132,7 @@ int main(int argc, char** argv) {
             a.variant = v;
             if (v == 0) { a.A = C0f; a.W0f = W0f; a.ea_in = ea0; a.ea_ld = 64; a.ea_out = ea1; a.evp_in = evp; a.eb = b; }
             if (v == 2) { a.C = nullptr; a.W4f = W4f; a.evp_out = evp; }
-            hipLaunchKernelGGL((fql_chain_kernel<512>), dim3(256), dim3(512), FQL_CHAIN_LDS_BYTES(512), s, a);
+            launch_chain(s, a);
         }
         CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         printf("new chain kernel, variant %c alone: %.2f us per launch\n", v == 0 ? 'A' : 'C', time_graph(s, ge, 96));

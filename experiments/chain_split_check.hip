@@ -95,16 +95,20 @@ int main() {
             a.ea_in = ea_in; a.ea_out = ea_out[v]; a.W0f = W0f[v]; a.evp_in = evp_in; a.eb = eb;
             a.W4f = W4f[v]; a.evp_out = evp_out[v];
             a.M = M; a.ad = ad; a.ap = ap; a.ea_ld = 48; a.inv_steps = 0.1f; a.t_s = 0.3f; a.variant = variant; a.tl = -1; a.prio = 0; a.stamps = nullptr;
-            if (v == 0) hipLaunchKernelGGL((fql_chain_kernel<512>), dim3((M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, a);
-            else hipLaunchKernelGGL((fql_chain_split_kernel<512>), dim3((M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, a);
+            if (v == 0) { if (variant == 0) hipLaunchKernelGGL((fql_chain_kernel<512, 0>), dim3((M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, a); else if (variant == 1) hipLaunchKernelGGL((fql_chain_kernel<512, 1>), dim3((M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, a); else hipLaunchKernelGGL((fql_chain_kernel<512, 2>), dim3((M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, a); }
+            else if (variant == 0) hipLaunchKernelGGL((fql_chain_split_kernel<512, 0>), dim3((M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, a);
+            else if (variant == 1) hipLaunchKernelGGL((fql_chain_split_kernel<512, 1>), dim3((M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, a);
+            else hipLaunchKernelGGL((fql_chain_split_kernel<512, 2>), dim3((M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, a);
             CK(hipGetLastError());
             CK(hipStreamSynchronize(s));
             // timing: 96 launches per graph
             hipGraph_t g; hipGraphExec_t ge;
             CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             for (int i = 0; i < 96; ++i) {
-                if (v == 0) hipLaunchKernelGGL((fql_chain_kernel<512>), dim3((M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, a);
-                else hipLaunchKernelGGL((fql_chain_split_kernel<512>), dim3((M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, a);
+                if (v == 0) { if (variant == 0) hipLaunchKernelGGL((fql_chain_kernel<512, 0>), dim3((M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, a); else if (variant == 1) hipLaunchKernelGGL((fql_chain_kernel<512, 1>), dim3((M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, a); else hipLaunchKernelGGL((fql_chain_kernel<512, 2>), dim3((M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, a); }
+                else if (variant == 0) hipLaunchKernelGGL((fql_chain_split_kernel<512, 0>), dim3((M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, a);
+            else if (variant == 1) hipLaunchKernelGGL((fql_chain_split_kernel<512, 1>), dim3((M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, a);
+            else hipLaunchKernelGGL((fql_chain_split_kernel<512, 2>), dim3((M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, a);
             }
             CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
             for (int i = 0; i < 10; ++i) CK(hipGraphLaunch(ge, s));

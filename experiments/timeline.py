@@ -20,7 +20,7 @@ TYPES = ['gemm16', 'side', 'wgrad', 'lnbwd', 'prep', 'postos', 'euler_fin', 'pec
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 od, ad, B = 29, 8, 256
 cfg = fql_amd.get_config()
-cfg.update(alpha=10.0, batch_size=B)
+cfg.update(alpha=10.0, batch_size=B, precision=os.environ.get('FQL_TL_PRECISION', 'fp32'))
 ds = make_synthetic_dataset(100_000, od, ad, seed=0)
 agent = fql_amd.FQLAgent.create(0, ds['observations'][:1], ds['actions'][:1], cfg)
 agent.upload_dataset(ds)

@@ -45,7 +45,11 @@ struct ChainArgs {
     float* evp_out;       // [H/32][M][ap]
     int M, ad, ap, ea_ld;
     float inv_steps, t_s;
-    int variant;          // 0 = A, 1 = B, 2 = C
+    int variant;          // 0 = A, 1 = B, 2 = C, 3 = D (below)
+    // variant D: an input-gradient layer of a plain (un-normalised) MLP as a chain launch, dX = (dZ W^T) * GELU'(z_prev)
+    // (utils/flax_utils.py:137 through utils/networks.py:53-58): A = dZ [M, H]; Wf = the ROW-MAJOR kernel W[j][n] - a lane's four
+    // contraction values n = 16 g + 4 q + s of output column j are 16 contiguous bytes there, no copy needed; no bias, no GELU
+    const float* Zprev;   // [M, H] stored GELU'(z) of the previous layer
     int tl;               // timeline id (diagnostics build)
     int prio;             // s_setprio level of the chain's waves (they are latency-critical and light: 0.85 us of MFMA per launch)
     unsigned long long* stamps;   // diagnostics build only (FQL_STAMPS): [grid][8] wall-clock stamps
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_wfrag_kernel(const WfragTask*
     stg4(T.dst + ((size_t)k4 * T.N + n) * 4, v);
 }
 
-template <int H>
+template <int H, int V>   // V: the variant as a compile-time constant (each variant gets the register allocation of its own code)
 __global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_kernel(const ChainArgs P) {
     static_assert(H % 128 == 0 && H <= 1024, "hidden width must be a multiple of 128");
     constexpr int S = H + 4;          // LDS row stride of the A tile (floats)
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_
     const int nt = wave & 1, kp = wave >> 1;
     const int tm = blockIdx.x / NT, tn = blockIdx.x - tm * NT;
     const int row0 = tm * 16, n0 = tn * 32 + nt * 16;
-    const int variant = P.variant;
+    constexpr int variant = V;
     tl_enter(P.tl);
     if (P.prio == 3) __builtin_amdgcn_s_setprio(3);
     else if (P.prio == 2) __builtin_amdgcn_s_setprio(2);
@@ -135,11 +139,18 @@ __global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_
     // ---- every load of the launch that does not depend on another workgroup's data of THIS launch goes out first
     f32x4 bf[GQ];
     {
-        const float* wb = P.Wf + ((size_t)(4 * kp * GQ + q) * H + n0 + c) * 4;
+        if (variant == 3) {   // row-major kernel read transposed: output column j = n0 + c, contraction n = 16 (kp GQ + g) + 4 q + s
+            const float* wb = P.Wf + (size_t)(n0 + c) * H + 16 * kp * GQ + 4 * q;
 #pragma unroll
-        for (int g = 0; g < GQ; ++g) bf[g] = ldg4(wb + (size_t)g * 16 * H);   // k-group kp GQ + g: rows 4 (kp GQ + g) + q of Wf
+            for (int g = 0; g < GQ; ++g) bf[g] = ldg4(wb + 16 * g);
+        } else {
+            const float* wb = P.Wf + ((size_t)(4 * kp * GQ + q) * H + n0 + c) * 4;
+#pragma unroll
+            for (int g = 0; g < GQ; ++g) bf[g] = ldg4(wb + (size_t)g * 16 * H);   // k-group kp GQ + g: rows 4 (kp GQ + g) + q of Wf
+        }
     }
-    const float bias = ldg(P.bias + n0 + c);
+    // epilogue operand of this lane's output element (row 4q + kp, column n0 + c): the bias, or GELU'(z_prev) for variant D
+    const float bias = variant == 3 ? ldg(P.Zprev + (size_t)(row0 + 4 * q + kp) * H + n0 + c) : ldg(P.bias + n0 + c);
     f32x4 bw4[2];
     if (variant == 2 && wave == 0) {
 #pragma unroll
@@ -226,10 +237,10 @@ __global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_
     CSTAMP();
     __syncthreads();
     // ---- epilogue shared by the 8 waves: wave (nt, kp) finishes row 4q + kp, column n0 + c of its column tile
-    float v = bias;
+    float v = variant == 3 ? 0.f : bias;
 #pragma unroll
     for (int p = 0; p < 4; ++p) v += red[((p * 2 + nt) * 64 + lane) * 4 + kp];
-    v = gelu_f(v);
+    v = variant == 3 ? v * bias : gelu_f(v);
     const int row = row0 + 4 * q + kp;
     if (variant != 2) {
         stg(P.C + (size_t)row * H + n0 + c, v);
@@ -280,8 +291,16 @@ __device__ __forceinline__ float lane_xor1(float v) {
 // lo plane of the same shape (the bytes of the fp32 tensor; the buffers are private to the chain).  The producer's epilogue splits
 // each value once (lanes c, c ^ 1 pair up: the even one stores the hi word, the odd one the lo word); the consumer's staging is
 // 16-byte copies into the swizzled LDS planes, no arithmetic.
-template <int H>
-__global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_split_kernel(const ChainArgs P) {
+// V: the variant as a compile-time constant, so each variant gets the register allocation of its own code: B and C need 62 / 61
+// registers, A 89.  Why it matters: a side-lane workgroup holds 168 registers per SIMD and a chain workgroup two waves per SIMD, so
+// next to TWO resident side workgroups a chain workgroup fits only with <= 88 registers per wave (2 x 88 + 2 x 168 = 512); at 104
+// (one kernel for all variants) every chain launch waited ~2 us for CUs to drain to one side workgroup (steady-state timeline).
+// Variant A is capped at 80 (6 waves per SIMD: two spilled values).
+#ifndef FQL_CHAIN_SPLIT_WAVES_A
+#define FQL_CHAIN_SPLIT_WAVES_A 4
+#endif
+template <int H, int V>
+__global__ __launch_bounds__(FQL_CHAIN_THREADS, (V == 0 ? FQL_CHAIN_SPLIT_WAVES_A : 4)) void fql_chain_split_kernel(const ChainArgs P) {
     static_assert(H % 128 == 0 && H <= 1024, "hidden width must be a multiple of 128");
     constexpr int RS = H / 2;         // words per row of an A plane
     constexpr int NS = H / 128;       // 32-deep MFMA steps per K-quarter
@@ -299,7 +318,7 @@ __global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_
     const int nt = wave & 1, kp = wave >> 1;
     const int tm = blockIdx.x / NT, tn = blockIdx.x - tm * NT;
     const int row0 = tm * 16, n0 = tn * 32 + nt * 16;
-    const int variant = P.variant;
+    constexpr int variant = V;
     tl_enter(P.tl);
     // ---- every load of the launch that does not depend on another workgroup's data of THIS launch goes out first
     u32x4 bh[NS], bl[NS];

@@ -1286,6 +1286,20 @@ struct fql_engine {
                 op.reads.push_back(p.z[l - 1]);
                 op.writes = {t.C};
                 if (want64(t.M, t.N, t.K, t.flags)) op.type = OP_GEMM64;
+                // a square hidden layer on the latency lane (the one-step actor's backward tail behind the Euler chain): the chain
+                // kernel's variant D does it in about half the time of the generic 16-row kernel
+                static const bool chain_dgrad = getenv("FQL_NO_CHAIN_DGRAD") == nullptr;
+                if (chain_dgrad && op.type == OP_GEMM && use_chain && t.N == t.K && t.N == cfg.actor_hidden[0] && t.M % 16 == 0 &&
+                    t.lda == t.K && t.ldb == t.K && t.ldc == t.N && prev.out_p == t.N) {
+                    Op co{};
+                    co.type = OP_CHAIN;
+                    ChainArgs& a = co.chain;
+                    a.A = t.A; a.Wf = t.B; a.C = t.C; a.Zprev = t.Zprev; a.bias = nullptr;
+                    a.M = t.M; a.ad = cfg.act_dim; a.ap = pad16(cfg.act_dim);
+                    a.variant = 3;
+                    co.reads = op.reads; co.writes = op.writes;
+                    push(pr, co);
+                } else
                 push(pr, op);
             }
         }
@@ -1771,12 +1785,18 @@ struct fql_engine {
             }
             case OP_CHAIN: {
                 ChainArgs ca = L.op.chain; ca.tl = tl;
-                if (cfg.precision == 2) {
-                    if (cfg.actor_hidden[0] == 512) FQL_LAUNCH((fql_chain_split_kernel<512>), dim3((L.op.chain.M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, ca);
-                    else FQL_LAUNCH((fql_chain_split_kernel<256>), dim3((L.op.chain.M / 16) * 8), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(256), s, ca);
+                if (cfg.precision == 2 && ca.variant != 3) {   // (variant D keeps fp32 operands: its dZ / W arrive as fp32 and splitting both in the kernel costs what the MFMAs save)
+#define FQL_CHAIN_SPLIT(HH, VV) FQL_LAUNCH((fql_chain_split_kernel<HH, VV>), dim3((L.op.chain.M / 16) * (HH / 32)), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(HH), s, ca)
+                    if (cfg.actor_hidden[0] == 512) { if (ca.variant == 0) FQL_CHAIN_SPLIT(512, 0); else if (ca.variant == 1) FQL_CHAIN_SPLIT(512, 1); else FQL_CHAIN_SPLIT(512, 2); }
+                    else { if (ca.variant == 0) FQL_CHAIN_SPLIT(256, 0); else if (ca.variant == 1) FQL_CHAIN_SPLIT(256, 1); else FQL_CHAIN_SPLIT(256, 2); }
+#undef FQL_CHAIN_SPLIT
                 }
-                else if (cfg.actor_hidden[0] == 512) FQL_LAUNCH((fql_chain_kernel<512>), dim3((L.op.chain.M / 16) * 16), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, ca);
-                else FQL_LAUNCH((fql_chain_kernel<256>), dim3((L.op.chain.M / 16) * 8), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(256), s, ca);
+                else {
+#define FQL_CHAIN_F32(HH, VV) FQL_LAUNCH((fql_chain_kernel<HH, VV>), dim3((L.op.chain.M / 16) * (HH / 32)), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(HH), s, ca)
+                    if (cfg.actor_hidden[0] == 512) { if (ca.variant == 0) FQL_CHAIN_F32(512, 0); else if (ca.variant == 1) FQL_CHAIN_F32(512, 1); else if (ca.variant == 2) FQL_CHAIN_F32(512, 2); else FQL_CHAIN_F32(512, 3); }
+                    else { if (ca.variant == 0) FQL_CHAIN_F32(256, 0); else if (ca.variant == 1) FQL_CHAIN_F32(256, 1); else if (ca.variant == 2) FQL_CHAIN_F32(256, 2); else FQL_CHAIN_F32(256, 3); }
+#undef FQL_CHAIN_F32
+                }
                 break;
             }
             case OP_WFRAG:
