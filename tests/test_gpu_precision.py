@@ -98,3 +98,21 @@ def test_unknown_precisions_are_refused():
     c.obs_dim, c.act_dim, c.precision = 29, 8, 1
     h = C.c_void_p()
     assert lib.fql_create(C.byref(c), 0, C.byref(h)) != 0
+
+
+def test_bf16x3_visual_agent_infos_follow_the_oracle():
+    """impala_small encoders + precision 'bf16x3': the convolutions stay on the fp32 matrix cores, the encoder's Dense and the MLPs run
+    split.  Infos within the visual test's bounds (tests/test_gpu_visual.py: 1e-4 relative + 1e-5) over three updates."""
+    from tests.test_gpu_visual import make_visual
+    from tests.util import assert_info_close
+    cfg, batch, _ = make_visual(precision='bf16x3')
+    B, ad = 32, 4
+    agent = _agent(cfg, batch)
+    params = randomize_params(agent.get_params(), seed=3, scale=0.05)
+    agent.set_params(params)
+    ref = O.OracleFQL(params, dict(cfg), (32, 32, 3), ad, np.float64)
+    for s in range(3):
+        nz = O.make_noise(B, ad, 50 + s)
+        _, ig = agent.update(batch, noise=nz)
+        _, ir = ref.update(batch, nz)
+        assert_info_close(ig, ir, rtol=5e-4, atol=5e-5)
