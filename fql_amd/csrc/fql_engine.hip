@@ -2166,7 +2166,8 @@ struct fql_engine {
         for (int e = 0; e < 2; ++e) emit_forward(pr, p_c1[e], with_grads);
         // three lanes: the target-critic pass rides on lane 1 (its action block comes from the one-step forward there, and lane 1 is otherwise
         // idle once the Q-gradient path has ended): 2500 -> 2580 updates/s in steady state
-        place("ct", lanes3 ? 1 : fill_lane, true);
+        static const int ct_lane3 = getenv("FQL_CT_LANE3") ? atoi(getenv("FQL_CT_LANE3")) : -1;   // (three-lane programs only: the others have no lane 2)
+        place("ct", lanes3 ? (ct_lane3 >= 0 ? ct_lane3 : 1) : fill_lane, true);
         for (int e = 0; e < 2; ++e) emit_forward(pr, p_ct[e], false);
         place("c1", fill_lane, true);
         {
@@ -2305,11 +2306,16 @@ struct fql_engine {
                 for (const void* r : {(const void*)p_os.out, (const void*)tgt, (const void*)p_c2[0].dx0, (const void*)p_c2[1].dx0}) d.reads.push_back(r);
                 d.writes.push_back(da);
             }
+            // Three lanes: lane 2 is idle by the time the tail runs, so each layer's weight gradient goes there as soon as its dz exists
+            // (beside the remaining dgrads of the tail); only the first layer's small one is left behind the last dgrad.
+            static const int os_w_l2_env = getenv("FQL_OS_WGRAD_LANE2") ? atoi(getenv("FQL_OS_WGRAD_LANE2")) : -1;
+            const bool os_w_l2 = lanes3 && (os_w_l2_env >= 0 ? os_w_l2_env != 0 : false);
             for (Op& w : os_w) {
-                w.reads.push_back(p_os_bwd.dz[0]);   // after the last dgrad: all five in one launch
-                emit_lane = 0;
+                if (!os_w_l2) w.reads.push_back(p_os_bwd.dz[0]);   // after the last dgrad: all five in one launch
+                emit_lane = os_w_l2 ? 2 : 0;
                 push(pr, w);
             }
+            emit_lane = 0;
         }
         if (with_grads && visual) {   // the obs half of the [obs ; next_obs] pass
             place("enc", split_build ? 0 : 1, true);
