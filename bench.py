@@ -99,6 +99,7 @@ def profile_kernels(agent, B, reps, split=False):
     if split:   # precision = 2 launches the split bodies for the side lanes and the Euler chain (the tail's input-gradient chain launches stay fp32)
         names[OP_NAMES.index('fql_side_kernel')] = 'fql_side_split_kernel'
         names[OP_NAMES.index('fql_chain_kernel')] = 'fql_chain_split_kernel (+ 3 fp32 fql_chain_kernel dgrad launches)'
+        names[OP_NAMES.index('fql_conv3x3_kernel')] = 'fql_conv3x3_split_kernel'
     from fql_amd import _cabi
     lib = _cabi.load()
     f = lib.fql_profile_update
@@ -238,7 +239,7 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     od, ad, B = args.obs_dim, args.act_dim, args.batch
-    peak_tf = FP32_MATRIX_PEAK_TFLOPS if args.precision == 'fp32' or args.workload == 'visual' else BF16_MATRIX_PEAK_TFLOPS / 3.0
+    peak_tf = FP32_MATRIX_PEAK_TFLOPS if args.precision == 'fp32' else BF16_MATRIX_PEAK_TFLOPS / 3.0
     cfg = fql_amd.get_config()
     visual = args.workload == 'visual'
     seed = 0    # the same seed on every rank: DataParallelFQL mixes the rank into the device RNG stream
@@ -248,7 +249,7 @@ def main():
         ad = 5
         args.rows = args.frames
         ds = make_synthetic_frames(args.frames, ad, seed=0)
-        cfg.update(alpha=300.0 if args.alpha is None else args.alpha, batch_size=B, encoder='impala_small')
+        cfg.update(alpha=300.0 if args.alpha is None else args.alpha, batch_size=B, encoder='impala_small', precision=args.precision)
         agent = fql_amd.FQLAgent.create(seed, np.zeros((1, 64, 64, 9), np.uint8), ds['actions'][:1], cfg)
         up_kw = dict(frame_stack=3, p_aug=0.5)
     else:
@@ -304,7 +305,7 @@ def main():
         out = {
             'metric': 'FQL gradient-steps/s (batch=256)', 'value': round(steps_per_s * world, 2), 'unit': 'grad-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt * 1e3 / args.steps, 5),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' or visual else 'bf16x3', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else ('bf16x3 (uint8 first convolution and convolution weight gradients: f32)' if visual else 'bf16x3'), 'data': 'synthetic',
             'config': {'workload': work, 'parallelism': f'dp{world}', 'samples_per_s': round(steps_per_s * world * B, 1)},
             'whole_update': {'flop': flop_per_step, 'wall_us': round(step_us_wall, 3), 'achieved_tflops': round(whole, 3),
                              ('frac_of_fp32_matrix_peak' if peak_tf == FP32_MATRIX_PEAK_TFLOPS else 'frac_of_bf16_matrix_peak_over_3'): round(whole / peak_tf, 4),
@@ -314,7 +315,7 @@ def main():
         roof = {'bound': 'mfma', 'achieved': round(whole, 3), 'peak': peak_tf, 'unit': 'TFLOP/s',
                 'frac': round(whole / peak_tf, 4), 'traffic': None, 'kernel': 'whole update (per-kernel pass skipped)'}
         if world == 1 and not args.no_extras:
-            fams = profile_kernels(agent, B, reps=20, split=(args.precision == 'bf16x3' and not visual))
+            fams = profile_kernels(agent, B, reps=20, split=(args.precision == 'bf16x3'))
             if fams:
                 mm = {k: v for k, v in fams.items() if v['flop_per_launch'] > 0}
                 dom = max(mm, key=lambda k: mm[k]['us_per_update'])

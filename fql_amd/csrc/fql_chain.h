@@ -278,11 +278,6 @@ __global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_
 // banks; with the swizzle both the b128 fragment reads and the b64 staging writes are conflict-free).  Per wave and K-quarter:
 // 3 x H/128 MFMAs of 16 cycles instead of H/16 of 32.
 // ------------------------------------------------------------------------------------------------
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u32x4 ldg4u(const unsigned* p) { return *(const FQL_GAS u32x4*)p; }
-__device__ __forceinline__ f32x4 mfma_bf16_k16(const u32x2& a, const u32x2& b, const f32x4& acc) {
-    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), acc, 0, 0, 0);
-}
 // value of the lane whose column index differs in bit 0 (DPP quad_perm [1, 0, 3, 2]: no LDS crossbar round trip)
 __device__ __forceinline__ float lane_xor1(float v) {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));

@@ -268,6 +268,149 @@ __global__ __launch_bounds__(FQL_THREADS, 3) void fql_conv3x3_u8_kernel(const Co
 }
 
 // ------------------------------------------------------------------------------------------------
+// precision = 2: the float convolutions (forward and data gradient) with split-bf16 operands (fql_kernels.h, top).
+// Same workgroup geometry, staging loop and epilogue as conv_body<., false>; the input rows are split ONCE by the thread that
+// stages them into hi / lo planes [(R+2)][(W+2)][3 Ci / 4 words] (Ci / 2 words of data + padding that makes the fragment reads
+// conflict-free: tools/lds_banks.py), the weights arrive pre-split from fql_conv_wprep_kernel as planes [Co][9 Ci / 2 + Ci / 4 words].
+// Ci = 32: one tap is one 32-deep step (lane (r, q) owns channels 8q .. 8q+7: 16-byte fragment reads, v_mfma_f32_16x16x32_bf16);
+// Ci = 16: one tap is one 16-deep step (channels 4q .. 4q+3: 8-byte reads, v_mfma_f32_16x16x16_bf16).  3 MFMAs per tap, row tile and
+// channel tile instead of Ci / 4 fp32 ones.
+// ------------------------------------------------------------------------------------------------
+template <int CO_TILES, int CI>
+__device__ __forceinline__ void conv_split_body(const ConvArgs& P, float* lds_f) {
+    constexpr int PSW = 3 * CI / 4, WSW = 9 * CI / 2 + CI / 4;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 15, q = lane >> 4;
+    const int H = P.H, W = P.W, Co = P.Co, R = P.R;
+    const int PW = W + 2;
+    const int IPL = (R + 2) * PW * PSW, WPL = Co * WSW;
+    unsigned* in_h = reinterpret_cast<unsigned*>(lds_f);   // [(R+2)][(W+2)][PSW]
+    unsigned* in_l = in_h + IPL;
+    unsigned* w_h = in_l + IPL;                             // [Co][WSW]
+    unsigned* w_l = w_h + WPL;
+    const int blocks_per_img = H / R;
+    const int nblocks = P.N * blocks_per_img;
+    const int wg = (int)blockIdx.x - P.tile0, nwg = P.nwg;
+    {   // weights -> LDS: hi plane then lo plane, a straight 16-byte copy (the padding words are zero in the copy)
+        const int total = (2 * WPL) >> 2;
+        const unsigned* src = reinterpret_cast<const unsigned*>(P.Wl);
+        for (int e = tid; e < total; e += FQL_THREADS) *reinterpret_cast<u32x4*>(w_h + 4 * e) = ldg4u(src + 4 * e);
+    }
+    {   // the padding words of the input planes are never written by the staging loop: clear them once (the fragment reads do not touch them either; tidy)
+        for (int e = tid; e < 2 * IPL; e += FQL_THREADS) in_h[e] = 0u;
+    }
+    const int ntiles = R * W / 16;
+    constexpr int KW = CI == 32 ? 4 : 2;   // words per fragment
+    int pbase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int t = min(wave + 4 * i, ntiles - 1);  // clamped: results of a duplicate tile are discarded
+        const int p = 16 * t + c;
+        pbase[i] = ((p / W) * PW + (p % W)) * PSW + KW * q;
+    }
+    float bv[CO_TILES];
+#pragma unroll
+    for (int j = 0; j < CO_TILES; ++j) bv[j] = P.bias ? ldg(P.bias + 16 * j + c) : 0.f;
+    int wbase[CO_TILES];
+#pragma unroll
+    for (int j = 0; j < CO_TILES; ++j) wbase[j] = (16 * j + c) * WSW + KW * q;
+
+    for (int blk = wg; blk < nblocks; blk += nwg) {
+        const int n = blk / blocks_per_img, y0 = (blk % blocks_per_img) * R;
+        __syncthreads();
+        {
+            const float* src = (const float*)P.in + (size_t)n * H * W * CI;
+            constexpr int c4 = CI >> 2;
+            const int total = (R + 2) * PW * c4;
+            for (int e = tid; e < total; e += FQL_THREADS) {
+                const int cc = e % c4, px = e / c4, xx = px % PW - 1, yy = y0 + px / PW - 1;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
+                    v = ldg4(src + ((size_t)yy * W + xx) * CI + 4 * cc);
+                    if (P.in_mode == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                }
+                u32x2 hi, lo;
+                bsplit4(v, hi, lo);
+                *reinterpret_cast<u32x2*>(in_h + px * PSW + 2 * cc) = hi;
+                *reinterpret_cast<u32x2*>(in_l + px * PSW + 2 * cc) = lo;
+            }
+        }
+        __syncthreads();
+        f32x4 acc[2][CO_TILES];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < CO_TILES; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 9; ++t) {
+            const int toff = ((t / 3) * PW + (t % 3)) * PSW;
+            if constexpr (CI == 32) {
+                u32x4 ah[2], al[2], bh[CO_TILES], bl[CO_TILES];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { ah[i] = *reinterpret_cast<const u32x4*>(in_h + pbase[i] + toff); al[i] = *reinterpret_cast<const u32x4*>(in_l + pbase[i] + toff); }
+#pragma unroll
+                for (int j = 0; j < CO_TILES; ++j) { bh[j] = *reinterpret_cast<const u32x4*>(w_h + wbase[j] + 16 * t); bl[j] = *reinterpret_cast<const u32x4*>(w_l + wbase[j] + 16 * t); }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16(al[i], bh[j], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16(ah[i], bl[j], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16(ah[i], bh[j], acc[i][j]);
+            } else {
+                u32x2 ah[2], al[2], bh[CO_TILES], bl[CO_TILES];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { ah[i] = *reinterpret_cast<const u32x2*>(in_h + pbase[i] + toff); al[i] = *reinterpret_cast<const u32x2*>(in_l + pbase[i] + toff); }
+#pragma unroll
+                for (int j = 0; j < CO_TILES; ++j) { bh[j] = *reinterpret_cast<const u32x2*>(w_h + wbase[j] + 8 * t); bl[j] = *reinterpret_cast<const u32x2*>(w_l + wbase[j] + 8 * t); }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16_k16(al[i], bh[j], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16_k16(ah[i], bl[j], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16_k16(ah[i], bh[j], acc[i][j]);
+            }
+        }
+        // ---- epilogue (that of conv_body).  C layout: col = lane & 15 (channel), row = 4 q + r (pixel of the tile)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int t = wave + 4 * i;
+            if (t >= ntiles) continue;
+#pragma unroll
+            for (int j = 0; j < CO_TILES; ++j) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int p = 16 * t + 4 * q + r;
+                    const size_t o = (((size_t)n * H + y0 + p / W) * W + (p % W)) * Co + 16 * j + c;
+                    float v = acc[i][j][r] + bv[j];
+                    if (P.mask) v = (ldg(P.mask + o) > 0.f) ? v : 0.f;
+                    if (P.add) v += ldg(P.add + o);
+                    stg(P.out + o, v);
+                    if (P.out_relu) stg(P.out_relu + o, fmaxf(v, 0.f));
+                }
+            }
+        }
+    }  // row blocks
+}
+#define FQL_CONV_SPLIT_LDS_WORDS(R, W, Ci, Co) (2 * ((R) + 2) * ((W) + 2) * (3 * (Ci) / 4) + 2 * (Co) * (9 * (Ci) / 2 + (Ci) / 4))
+__global__ __launch_bounds__(FQL_THREADS, FQL_CONV_WAVES) void fql_conv3x3_split_kernel(const ConvArgs* __restrict__ tasks, int ntasks) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const ConvArgs& P = tasks[find_task(tasks, ntasks, blockIdx.x)];
+    if (P.Ci == 32) { if (P.Co == 32) conv_split_body<2, 32>(P, lds); else conv_split_body<1, 32>(P, lds); }
+    else { if (P.Co == 32) conv_split_body<2, 16>(P, lds); else conv_split_body<1, 16>(P, lds); }
+}
+
+// ------------------------------------------------------------------------------------------------
 // conv3x3 weight gradient: dK[t][c][o] = sum_{n,y,x} f(in[n,y+ty-1,x+tx-1,c]) dOut[n,y,x,o], db[o] = sum dOut.
 // Contraction over N H W pixels: every workgroup walks its share of the (image, row block) list with the input rows and
 // the dOut rows in LDS (the next block's rows are already in flight, see ConvTile).  The 9 (Ci/16) (tap, input-channel
@@ -608,7 +751,18 @@ struct ConvWprepTask {
     float* Wf;
     float* Wb;   // null: no data gradient needed (first convolution)
     int cin, cout, Ci;
+    int split;   // precision = 2, float convolutions: Wf / Wb are bf16 hi / lo planes [rows][9 C / 2 + C / 4 words] (C = channels per tap) for
+                 // fql_conv3x3_split_kernel instead of the fp32 [rows][9 C + 4] image (the uint8 first layer keeps the fp32 image)
 };
+__device__ __forceinline__ void wprep_store_split(float* planes, int rows, int C, int row, int k, float v) {
+    const int WSW = 9 * C / 2 + C / 4;
+    unsigned h, l;
+    bsplit2(v, 0.f, h, l);
+    unsigned short* hp = reinterpret_cast<unsigned short*>(planes);
+    unsigned short* lp = hp + (size_t)2 * rows * WSW;
+    hp[(size_t)2 * row * WSW + k] = (unsigned short)(h & 0xFFFFu);
+    lp[(size_t)2 * row * WSW + k] = (unsigned short)(l & 0xFFFFu);
+}
 __global__ __launch_bounds__(FQL_THREADS) void fql_conv_wprep_kernel(const ConvWprepTask* __restrict__ tasks) {
     const ConvWprepTask T = tasks[blockIdx.y];
     const int total = 9 * T.cin * T.cout;
@@ -616,6 +770,11 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_conv_wprep_kernel(const ConvW
     for (int e = blockIdx.x * FQL_THREADS + threadIdx.x; e < total; e += gridDim.x * FQL_THREADS) {
         const int o = e % T.cout, r = e / T.cout, c = r % T.cin, t = r / T.cin;
         const float v = T.K[e];
+        if (T.split) {
+            wprep_store_split(T.Wf, T.cout, T.Ci, o, t * T.Ci + c, v);
+            if (T.Wb) wprep_store_split(T.Wb, T.cin, T.cout, c, (8 - t) * T.cout + o, v);
+            continue;
+        }
         T.Wf[(size_t)o * WSf + t * T.Ci + c] = v;
         if (T.Wb) T.Wb[(size_t)c * WSb + (8 - t) * T.cout + o] = v;
     }

@@ -89,6 +89,7 @@ struct ConvL {
     size_t w, b;
     int cin, cout;
     float *Wf = nullptr, *Wb = nullptr;   // LDS-layout copies refreshed by fql_conv_wprep_kernel at the start of each pass
+    bool split = false;                   // precision = 2: the copies are bf16 hi / lo planes (fql_conv3x3_split_kernel)
 };
 struct EncStack {
     std::vector<ConvL> conv;  // conv[0] at the stack's input resolution, the rest after the 2x max-pool
@@ -441,9 +442,12 @@ struct fql_engine {
             for (EncStack& st : encs[ei].stacks)
                 for (ConvL& c : st.conv) {
                     const int Ci = pad16c(c.cin);
-                    c.Wf = dalloc(enc_allocs, (size_t)c.cout * (9 * Ci + 4));
-                    c.Wb = first ? nullptr : dalloc(enc_allocs, (size_t)c.cin * (9 * c.cout + 4));   // no gradient into the images
-                    tasks.push_back(ConvWprepTask{P + c.w, c.Wf, c.Wb, c.cin, c.cout, Ci});
+                    // precision = 2: the float convolutions read pre-split bf16 hi / lo planes (slightly larger than the fp32 image)
+                    const bool split = cfg.precision == 2 && !first && (Ci == 16 || Ci == 32) && (c.cout == 16 || c.cout == 32);
+                    c.Wf = dalloc(enc_allocs, std::max((size_t)c.cout * (9 * Ci + 4), (size_t)2 * c.cout * (9 * Ci / 2 + Ci / 4)));
+                    c.Wb = first ? nullptr : dalloc(enc_allocs, std::max((size_t)c.cin * (9 * c.cout + 4), (size_t)2 * c.cin * (9 * c.cout / 2 + c.cout / 4)));   // no gradient into the images
+                    c.split = split;
+                    tasks.push_back(ConvWprepTask{P + c.w, c.Wf, c.Wb, c.cin, c.cout, Ci, split ? 1 : 0});
                     first = false;
                 }
             enc_nconv[ei] = (int)tasks.size();
@@ -1497,6 +1501,7 @@ struct fql_engine {
                             a.nwg = per_cu > 0 ? std::min(nb, std::max(1, (int)(((long long)per_cu * num_cus * nb) / nb_all))) : nb;
                             tile += a.nwg;
                             L.lds = std::max(L.lds, ((size_t)(a.R + 2) * (a.W + 2) * (a.Ci + 4) + (size_t)a.Co * (9 * a.Ci + 4)) * sizeof(float));
+                            if (ty == OP_CONV && cfg.precision == 2) L.lds = std::max(L.lds, (size_t)FQL_CONV_SPLIT_LDS_WORDS(a.R, a.W, a.Ci, a.Co) * sizeof(float));
                             tb.push_back(a);
                         }
                         L.table = up(tb.data(), tb.size() * sizeof(ConvArgs));
@@ -1755,6 +1760,8 @@ struct fql_engine {
                 FQL_LAUNCH(fql_conv_wprep_kernel, dim3(4, L.op.wprep_n), dim3(FQL_THREADS), 0, s, L.op.wprep_tasks);
                 break;
             case OP_CONV:
+                if (cfg.precision == 2) FQL_LAUNCH(fql_conv3x3_split_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
+                else
                 FQL_LAUNCH(fql_conv3x3_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
                 break;
             case OP_CONV_U8:

@@ -58,6 +58,11 @@ __device__ __forceinline__ void bsplit4(const f32x4& v, u32x2& hi, u32x2& lo) {
 __device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const f32x4& acc) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
 }
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma_bf16_k16(const u32x2& a, const u32x2& b, const f32x4& acc) {   // v_mfma_f32_16x16x16_bf16: lane (r, q) owns k = 4q .. 4q + 3
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ u32x4 ldg4u(const unsigned* p) { return *(const FQL_GAS u32x4*)p; }
 // transposed LDS read (ds_read_b64_tr_b16): within each group of 16 lanes, lane 4r + p supplies the address of row r, columns
 // 4p .. 4p+3 of a 4 x 16 block of 16-bit elements; lane i receives column i (element e = row e).  EXEC must be all ones.
 __device__ __forceinline__ u32x2 lds_read_tr16(const unsigned* p) {

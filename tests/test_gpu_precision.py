@@ -100,9 +100,11 @@ def test_unknown_precisions_are_refused():
     assert lib.fql_create(C.byref(c), 0, C.byref(h)) != 0
 
 
-def test_bf16x3_visual_agent_infos_follow_the_oracle():
-    """impala_small encoders + precision 'bf16x3': the convolutions stay on the fp32 matrix cores, the encoder's Dense and the MLPs run
-    split.  Infos within the visual test's bounds (tests/test_gpu_visual.py: 1e-4 relative + 1e-5) over three updates."""
+def test_bf16x3_visual_agent_follows_the_oracle():
+    """impala_small encoders + precision 'bf16x3': the float convolutions (forward, data gradient), the encoder's Dense and the MLPs run
+    split; the uint8 first convolution and the convolution weight gradients stay on the fp32 matrix cores.  Per-leaf gradients with the
+    visual test's structure (tests/test_gpu_visual.py: convolutions below a max-pool may deviate through a tie-break; every other leaf is
+    tight - here 2e-4 of the leaf's scale instead of 5e-5), then infos over further updates."""
     from tests.test_gpu_visual import make_visual
     from tests.util import assert_info_close
     cfg, batch, _ = make_visual(precision='bf16x3')
@@ -111,8 +113,27 @@ def test_bf16x3_visual_agent_infos_follow_the_oracle():
     params = randomize_params(agent.get_params(), seed=3, scale=0.05)
     agent.set_params(params)
     ref = O.OracleFQL(params, dict(cfg), (32, 32, 3), ad, np.float64)
-    for s in range(3):
-        nz = O.make_noise(B, ad, 50 + s)
+    nz = O.make_noise(B, ad, 50)
+    _, _, g_ref = ref.grads(batch, nz)
+    _, ig = agent.update(batch, noise=nz)
+    _, ir = ref.update(batch, nz)
+    assert_info_close(ig, ir, rtol=5e-4, atol=5e-5)
+    mu = leaf_dict(agent.get_opt_state()['mu'])
+    tight, loose = 0, []
+    for p, g in leaf_dict(g_ref).items():
+        if p.startswith('modules_target_critic'):
+            continue
+        scale = np.abs(g).max()
+        err = np.abs(mu[p] / 0.1 - g).max()
+        assert err <= 3e-2 * scale + 1e-9, (p, err / scale)
+        if err <= 2e-4 * scale + 1e-9:
+            tight += 1
+        else:
+            assert '/encoder/stack_blocks_' in p, (p, err / scale)
+            loose.append(p)
+    assert tight >= 3 * len(loose), loose
+    for s in range(2):
+        nz = O.make_noise(B, ad, 51 + s)
         _, ig = agent.update(batch, noise=nz)
         _, ir = ref.update(batch, nz)
-        assert_info_close(ig, ir, rtol=5e-4, atol=5e-5)
+        assert_info_close(ig, ir, rtol=1e-3, atol=1e-4)
