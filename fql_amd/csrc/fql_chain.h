@@ -34,15 +34,27 @@ struct ChainArgs {
     const float* Wf;      // fragment-major kernel of this launch's H x H layer: [H/4][H][4]
     const float* bias;    // [H]
     float* C;             // A, B: output activations [M, H] row-major
-    // variant A
-    const float* ea_in;   // [M, ea_ld] actions a_{s-1} (step 0: the noise z)
-    float* ea_out;        // [M, ap] a_s as used by this step (written by column tile 0) or null
-    const float* W0f;     // fragment-major W0 rows of (action block, t, zero padding): [4][H][4]
-    const float* evp_in;  // [H/32][M][ap] head partials of the previous step, or null (step 0)
-    const float* eb;      // [ap] head bias
-    // variant C
-    const float* W4f;     // fragment-major head kernel [H/4][ap][4]
-    float* evp_out;       // [H/32][M][ap]
+    union {
+        struct {   // variants A / C
+            const float* ea_in;   // [M, ea_ld] actions a_{s-1} (step 0: the noise z)
+            float* ea_out;        // [M, ap] a_s as used by this step (written by column tile 0) or null
+            const float* W0f;     // fragment-major W0 rows of (action block, t, zero padding): [4][H][4]
+            const float* evp_in;  // [H/32][M][ap] head partials of the previous step, or null (step 0)
+            const float* eb;      // [ap] head bias
+            const float* W4f;     // fragment-major head kernel [H/4][ap][4] (variant C)
+            float* evp_out;       // [H/32][M][ap] (variant C)
+        };
+        struct {   // variant E (below)
+            const float* Gv;      // [M, H] GELU(z) of the layer whose LayerNorm is differentiated = what the LayerNorm normalised
+            const float* stats;   // [M, 2] mean, rstd
+            const float* gamma;   // [H] LayerNorm scale
+            const float* dq;      // scalar head: dY[m][k] = dq[m ldq] wq[k ldw] when A is null, else unused
+            const float* wq;
+            int ldq, ldw;
+            int width;            // real (unpadded) layer width: LayerNorm statistics run over k < width
+            int ncol, ldc;        // output columns (multiple of 32; H for the hidden layers, the padded input width for layer 0) and row stride of C
+        };
+    };
     int M, ad, ap, ea_ld;
     float inv_steps, t_s;
     int variant;          // 0 = A, 1 = B, 2 = C, 3 = D (below)
@@ -50,6 +62,13 @@ struct ChainArgs {
     // (utils/flax_utils.py:137 through utils/networks.py:53-58): A = dZ [M, H]; Wf = the ROW-MAJOR kernel W[j][n] - a lane's four
     // contraction values n = 16 g + 4 q + s of output column j are 16 contiguous bytes there, no copy needed; no bias, no GELU
     const float* Zprev;   // [M, H] stored GELU'(z) of the previous layer
+    // variant E: one level of the input-gradient chain through a LayerNorm'd MLP (the critic's Q-gradient path, agents/fql.py:69-79 through
+    // utils/networks.py:53-58) in ONE launch instead of a LayerNorm-backward launch + a dgrad launch: the prologue rebuilds
+    //   dZ = rstd (d - mean(d) - xhat mean(d xhat)) GELU'(z),  d = dY gamma,  xhat = (GELU(z) - mean) rstd
+    // for the workgroup's 16 rows in LDS (whole rows are there, so the two row statistics need no second pass), then dX = dZ W^T with the
+    // row-major kernel as in variant D; no epilogue (the next level's prologue applies its own LayerNorm backward).  A = dY [M, H] or null
+    // (scalar head: dY = dq (x) wq), Zprev = GELU'(z), C = dX [M, ldc].  fp32 operands in both precisions.
+    int hw;               // variant E: hidden width of THIS launch's layers (the critic's; the other variants use the BC flow's)
     int tl;               // timeline id (diagnostics build)
     int prio;             // s_setprio level of the chain's waves (they are latency-critical and light: 0.85 us of MFMA per launch)
     unsigned long long* stamps;   // diagnostics build only (FQL_STAMPS): [grid][8] wall-clock stamps
@@ -107,7 +126,7 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_wfrag_kernel(const WfragTask*
 }
 
 template <int H, int V>   // V: the variant as a compile-time constant (each variant gets the register allocation of its own code)
-__global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_kernel(const ChainArgs P) {
+__device__ __forceinline__ void chain_body(const ChainArgs& P) {
     static_assert(H % 128 == 0 && H <= 1024, "hidden width must be a multiple of 128");
     constexpr int S = H + 4;          // LDS row stride of the A tile (floats)
     constexpr int GQ = H / 64;        // k-groups (of 16) per K-quarter
@@ -121,9 +140,10 @@ __global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 15, q = lane >> 4;
     const int nt = wave & 1, kp = wave >> 1;
-    const int tm = blockIdx.x / NT, tn = blockIdx.x - tm * NT;
-    const int row0 = tm * 16, n0 = tn * 32 + nt * 16;
     constexpr int variant = V;
+    const int ntc = variant == 4 ? P.ncol / 32 : NT;
+    const int tm = blockIdx.x / ntc, tn = blockIdx.x - tm * ntc;
+    const int row0 = tm * 16, n0 = tn * 32 + nt * 16;
     tl_enter(P.tl);
     if (P.prio == 3) __builtin_amdgcn_s_setprio(3);
     else if (P.prio == 2) __builtin_amdgcn_s_setprio(2);
@@ -139,7 +159,7 @@ __global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_
     // ---- every load of the launch that does not depend on another workgroup's data of THIS launch goes out first
     f32x4 bf[GQ];
     {
-        if (variant == 3) {   // row-major kernel read transposed: output column j = n0 + c, contraction n = 16 (kp GQ + g) + 4 q + s
+        if (variant == 3 || variant == 4) {   // row-major kernel read transposed: output column j = n0 + c, contraction n = 16 (kp GQ + g) + 4 q + s
             const float* wb = P.Wf + (size_t)(n0 + c) * H + 16 * kp * GQ + 4 * q;
 #pragma unroll
             for (int g = 0; g < GQ; ++g) bf[g] = ldg4(wb + 16 * g);
@@ -150,7 +170,7 @@ __global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_
         }
     }
     // epilogue operand of this lane's output element (row 4q + kp, column n0 + c): the bias, or GELU'(z_prev) for variant D
-    const float bias = variant == 3 ? ldg(P.Zprev + (size_t)(row0 + 4 * q + kp) * H + n0 + c) : ldg(P.bias + n0 + c);
+    const float bias = variant == 4 ? 0.f : variant == 3 ? ldg(P.Zprev + (size_t)(row0 + 4 * q + kp) * H + n0 + c) : ldg(P.bias + n0 + c);
     f32x4 bw4[2];
     if (variant == 2 && wave == 0) {
 #pragma unroll
@@ -202,6 +222,59 @@ __global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_
                 for (int i = 0; i < 4; ++i) lds[(4 * q + i) * S + 16 * ct + c] = gelu_f(cacc[t][i]);
             }
         }
+    } else if (variant == 4) {
+        // LayerNorm backward of the workgroup's 16 rows into the A tile: wave w owns rows 2w, 2w + 1; a lane owns the float4 columns
+        // 4 (lane + 64 i), i < H / 256, of both rows.  Every load first, then the two row sums per row by wave shuffles.
+        constexpr int NV = H / 256;
+        f32x4 dy[2][NV], zz[2][NV], gq[2][NV], gm[NV];
+        float mean[2], rstd[2];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) gm[i] = ldg4(P.gamma + 4 * (lane + 64 * i));
+        float wqv[NV][4];
+        if (!P.A) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wqv[i][e] = ldg(P.wq + (size_t)(4 * (lane + 64 * i) + e) * P.ldw);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const size_t row = (size_t)(row0 + 2 * wave + r);
+            mean[r] = ldg(P.stats + 2 * row); rstd[r] = ldg(P.stats + 2 * row + 1);
+            const float dqr = P.A ? 0.f : ldg(P.dq + row * P.ldq);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int k4 = 4 * (lane + 64 * i);
+                zz[r][i] = ldg4(P.Zprev + row * H + k4);
+                gq[r][i] = ldg4(P.Gv + row * H + k4);
+                if (P.A) dy[r][i] = ldg4(P.A + row * H + k4);
+                else dy[r][i] = f32x4{dqr * wqv[i][0], dqr * wqv[i][1], dqr * wqv[i][2], dqr * wqv[i][3]};
+            }
+        }
+        const float inv = 1.0f / (float)P.width;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = dy[r][i][e] * gm[i][e], xh = (gq[r][i][e] - mean[r]) * rstd[r];
+                    dy[r][i][e] = d; gq[r][i][e] = xh;
+                    if (4 * (lane + 64 * i) + e < P.width) { s1 += d; s2 += d * xh; }
+                }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            const float m1 = s1 * inv, m2 = s2 * inv;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[e] = (4 * (lane + 64 * i) + e < P.width) ? rstd[r] * (dy[r][i][e] - m1 - gq[r][i][e] * m2) * zz[r][i][e] : 0.f;
+                *reinterpret_cast<f32x4*>(&lds[(2 * wave + r) * S + 4 * (lane + 64 * i)]) = o;
+            }
+        }
     } else {
         f32x4 av[NA];
         const float* Ag = P.A + (size_t)row0 * H;
@@ -237,12 +310,14 @@ __global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_
     CSTAMP();
     __syncthreads();
     // ---- epilogue shared by the 8 waves: wave (nt, kp) finishes row 4q + kp, column n0 + c of its column tile
-    float v = variant == 3 ? 0.f : bias;
+    float v = (variant == 3 || variant == 4) ? 0.f : bias;
 #pragma unroll
     for (int p = 0; p < 4; ++p) v += red[((p * 2 + nt) * 64 + lane) * 4 + kp];
-    v = variant == 3 ? v * bias : gelu_f(v);
+    v = variant == 4 ? v : variant == 3 ? v * bias : gelu_f(v);
     const int row = row0 + 4 * q + kp;
-    if (variant != 2) {
+    if (variant == 4) {
+        stg(P.C + (size_t)row * P.ldc + n0 + c, v);
+    } else if (variant != 2) {
         stg(P.C + (size_t)row * H + n0 + c, v);
     } else {
         hs[(4 * q + kp) * 36 + 16 * nt + c] = v;
@@ -270,6 +345,12 @@ __global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_
     }
 #endif
 }
+template <int H, int V>
+__global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_kernel(const ChainArgs P) { chain_body<H, V>(P); }
+// two independent tasks of one variant in one launch (blockIdx.y picks the task): the two ensemble members of the critic's Q-gradient chain
+struct ChainPair { ChainArgs t[2]; };
+template <int H, int V>
+__global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_pair_kernel(const ChainPair P) { chain_body<H, V>(P.t[blockIdx.y]); }
 // ------------------------------------------------------------------------------------------------
 // precision = 2: the same three variants with split-bf16 operands (fql_kernels.h, top).  Weights arrive pre-split from
 // fql_wfrag_kernel (modes 1 / 2: one 16-byte hi and one 16-byte lo load per lane and 32-deep MFMA step, the bytes of the fp32

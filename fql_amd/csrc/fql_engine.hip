@@ -161,6 +161,8 @@ struct Launch {
     size_t lds = 0;
     void* table = nullptr;  // device task table (GEMM/WGRAD/LNBWD)
     Op op;                  // arg-struct kernels
+    ChainArgs chain2{};     // OP_CHAIN variant E: second task of the launch (the other ensemble member)
+    bool chain_pair = false;
     int lane = 0;
     bool tmt2 = false, kbig = false, euler = false;
     double macs = 0.0;           // algorithmic multiply-accumulates of the GEMM-shaped tasks of this launch (roofline accounting)
@@ -1195,6 +1197,44 @@ struct fql_engine {
         const Net& n = nets[p.net];
         const int L = n.nl() - 1;
         auto rows = [&](float* base, int ld) { return base + (size_t)row_off * ld; };
+        // Input-gradient-only pass through a LayerNorm'd MLP with a scalar head (the critic under the actor's Q term): every level
+        // (LayerNorm backward + dgrad) as ONE chain-kernel launch (variant E), the two ensemble members paired in a launch - 4 launches
+        // instead of 8 on the lane the one-step actor's tail waits for.  Built, parity-green and MEASURED SLOWER (bf16x3 3035 -> 2880,
+        // fp32 2580 -> 2546 updates/s: the 16 column-tile workgroups of a row tile each reload three [16 x H] operands and redo the row
+        // statistics), so it is opt-in: FQL_CHAIN_LN=1.
+        static const bool chain_ln = getenv("FQL_CHAIN_LN") != nullptr && atoi(getenv("FQL_CHAIN_LN")) != 0;
+        bool fuse_ln = chain_ln && !param_grads && input_grad && !visual && L >= 2 && n.layers[L].out == 1 && M % 16 == 0;
+        const int Hc = n.layers[0].out_p;
+        fuse_ln = fuse_ln && (Hc == 256 || Hc == 512) && n.layers[0].in_p % 32 == 0;
+        for (int l = 0; l < L && fuse_ln; ++l) fuse_ln = n.layers[l].ln && n.layers[l].out_p == Hc && (l == 0 || n.layers[l].in_p == Hc);
+        if (fuse_ln) {
+            for (int l = L - 1; l >= 0; --l) {
+                const Layer& ly = n.layers[l];
+                Op co{};
+                co.type = OP_CHAIN;
+                ChainArgs& a = co.chain;
+                a.variant = 4; a.hw = Hc; a.M = M;
+                if (l == L - 1) {
+                    const Layer& head = n.layers[L];
+                    a.A = nullptr; a.dq = p.dz[L]; a.ldq = head.out_p; a.wq = P + head.w; a.ldw = head.out_p;
+                    co.reads = {p.dz[L], a.wq};
+                } else {
+                    a.A = p.dy[l];
+                    co.reads = {p.dy[l]};
+                }
+                a.Zprev = rows(p.z[l], ly.out_p); a.Gv = rows(p.g[l], ly.out_p); a.stats = p.stats[l] + (size_t)row_off * 2; a.gamma = P + ly.g;
+                a.width = ly.out;
+                a.Wf = P + ly.w;
+                a.ncol = ly.in_p; a.ldc = ly.in_p;
+                a.C = (l == 0) ? p.dx0 : p.dy[l - 1];
+                for (const void* r : {(const void*)p.z[l], (const void*)p.g[l], (const void*)p.stats[l], (const void*)a.gamma, (const void*)a.Wf}) co.reads.push_back(r);
+                co.writes = {a.C};
+                push(pr, co);
+            }
+            if (align_with)
+                for (size_t i = first_op; i < pr.ops.size(); ++i) { pr.ops[i].reads.push_back(align_with); break; }
+            return;
+        }
         for (int l = L; l >= 0; --l) {
             const Layer& ly = n.layers[l];
             float* dz = p.dz[l];
@@ -1530,7 +1570,18 @@ struct fql_engine {
                     continue;
                 }
                 if (!is_table((OpType)ty)) {
+                    const Op* pending = nullptr;   // an OP_CHAIN variant-E op waiting for a partner of the same shape (fql_chain_pair_kernel)
                     for (const Op* o : sel) {
+                        if (ty == OP_CHAIN && o->chain.variant == 4) {
+                            if (pending && pending->chain.hw == o->chain.hw && pending->chain.ncol == o->chain.ncol && pending->chain.M == o->chain.M) {
+                                Launch& Lp = pr.launches[launch_of[pending - pr.ops.data()]];
+                                Lp.chain2 = o->chain; Lp.chain_pair = true;
+                                launch_of[o - pr.ops.data()] = launch_of[pending - pr.ops.data()];
+                                pending = nullptr;
+                                continue;
+                            }
+                            pending = o;
+                        }
                         Launch L;
                         L.type = (OpType)ty;
                         L.op = *o;
@@ -1642,6 +1693,7 @@ struct fql_engine {
             else if (o.type == OP_CHAIN) {
                 const double H = cfg.actor_hidden[0];
                 m = (double)o.chain.M * H * H + (o.chain.variant == 0 ? (double)o.chain.M * 16.0 * H : 0.0) + (o.chain.variant == 2 ? (double)o.chain.M * H * o.chain.ap : 0.0);
+                if (o.chain.variant == 4) m = (double)o.chain.M * o.chain.hw * o.chain.ncol;
             }
             else if (o.type == OP_CONV || o.type == OP_CONV_U8) m = (double)o.conv.N * o.conv.H * o.conv.W * 9.0 * (o.conv.transposed ? o.conv.Ci : o.conv.Ci_real) * o.conv.Co;
             else if (o.type == OP_CONV_WGRAD) m = (double)o.cw.N * o.cw.H * o.cw.W * 9.0 * o.cw.Ci_real * o.cw.Co;
@@ -1792,6 +1844,18 @@ struct fql_engine {
             }
             case OP_CHAIN: {
                 ChainArgs ca = L.op.chain; ca.tl = tl;
+                if (ca.variant == 4) {   // fused LayerNorm-backward + dgrad level of the critic's Q-gradient chain (fp32 operands in both precisions)
+                    const dim3 g4((ca.M / 16) * (ca.ncol / 32), L.chain_pair ? 2 : 1);
+                    if (L.chain_pair) {
+                        ChainPair cp; cp.t[0] = ca; cp.t[1] = L.chain2; cp.t[1].tl = tl;
+                        if (ca.hw == 512) FQL_LAUNCH((fql_chain_pair_kernel<512, 4>), g4, dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, cp);
+                        else FQL_LAUNCH((fql_chain_pair_kernel<256, 4>), g4, dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(256), s, cp);
+                    } else {
+                        if (ca.hw == 512) FQL_LAUNCH((fql_chain_kernel<512, 4>), g4, dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, ca);
+                        else FQL_LAUNCH((fql_chain_kernel<256, 4>), g4, dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(256), s, ca);
+                    }
+                    break;
+                }
                 if (cfg.precision == 2 && ca.variant != 3) {   // (variant D keeps fp32 operands: its dZ / W arrive as fp32 and splitting both in the kernel costs what the MFMAs save)
 #define FQL_CHAIN_SPLIT(HH, VV) FQL_LAUNCH((fql_chain_split_kernel<HH, VV>), dim3((L.op.chain.M / 16) * (HH / 32)), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(HH), s, ca)
                     if (cfg.actor_hidden[0] == 512) { if (ca.variant == 0) FQL_CHAIN_SPLIT(512, 0); else if (ca.variant == 1) FQL_CHAIN_SPLIT(512, 1); else FQL_CHAIN_SPLIT(512, 2); }

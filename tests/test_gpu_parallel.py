@@ -98,11 +98,13 @@ def test_replay_ring_insert():
     assert a.dataset_size() == (7, 1)
 
 
-def test_split_lane_update_matches_plain_update():
-    """fql_update_begin_split (lane graphs on two streams, bucketed gradients) must give the same step as fql_update."""
+@pytest.mark.parametrize('precision,H', [('fp32', 64), ('bf16x3', 64), ('fp32', 256), ('bf16x3', 256)])
+def test_split_lane_update_matches_plain_update(precision, H):
+    """fql_update_begin_split (lane graphs on two streams, bucketed gradients) must give the same step as fql_update - in both precisions,
+    and at a width where the Euler chain / tail dgrads run on the chain kernels (H = 256)."""
     import fql_amd
     od, ad, B = 29, 8, 64
-    cfg, ds, batch, noise = make_problem(od, ad, B, (64, 64, 64, 64), seed=23)
+    cfg, ds, batch, noise = make_problem(od, ad, B, (H, H, H, H), seed=23, precision=precision)
     a = fql_amd.FQLAgent.create(0, batch['observations'][:1], batch['actions'][:1], cfg)
     b = fql_amd.FQLAgent.create(0, batch['observations'][:1], batch['actions'][:1], cfg)
     b.set_params(a.get_params())
@@ -120,11 +122,20 @@ def test_split_lane_update_matches_plain_update():
         b.update_end(stream=s0.cuda_stream)
         torch.cuda.synchronize()
         ia, ib = a.read_info(), b.read_info()
+        # fp32: the two programs run the same fp32 fma chains (only the lane structure differs).  bf16x3: the two-lane program leaves some
+        # products on the 16-row fp32 kernel that the three-lane program runs on the split side tiles, so the two agree to the split's own
+        # accuracy (~1e-5), not to rounding
+        tol = 1e-6 if precision == 'fp32' else 5e-5
         for k in ia:
-            assert abs(ia[k] - ib[k]) <= 1e-6 * max(1.0, abs(ia[k])), (step, k, ia[k], ib[k])
+            assert abs(ia[k] - ib[k]) <= tol * max(1.0, abs(ia[k])), (step, k, ia[k], ib[k])
     pa, pb = (dict(O.tree_leaves_with_path(x.get_params())) for x in (a, b))
     for p in pa:
-        np.testing.assert_allclose(pb[p], pa[p], rtol=0, atol=1e-7, err_msg=p)
+        if precision == 'fp32':
+            np.testing.assert_allclose(pb[p], pa[p], rtol=0, atol=1e-7, err_msg=p)
+        else:   # Adam's first steps are sign-like where |g| ~ 0: a few elements may differ by up to 2 lr per step, the rest are tight
+            d = np.abs(pb[p] - pa[p])
+            assert d.max() <= 3 * 2 * cfg['lr'] + 1e-6, (p, d.max())
+            assert (d <= 2e-5).mean() >= 0.99, (p, (d <= 2e-5).mean())
 
 
 def test_dataset_mirror_attached_to_engine():
