@@ -426,7 +426,10 @@ struct ConvWgradArgs {
     int tile0, nwg;
 };
 
-template <int CI_TILES, int CO_TILES, bool U8>
+// SPLIT (precision = 2, float inputs): the LDS images and the staging stay fp32; the 8 pixels a lane holds per TWO pixel groups for a unit's
+// input fragment and for each dOut column tile are one 16x16x32 operand each (the k order inside a step is free as long as both operands
+// share it), split in registers: 3 bf16 MFMAs per unit and column tile per 32 pixels instead of 8 fp32 ones.
+template <int CI_TILES, int CO_TILES, bool U8, bool SPLIT = false>
 __device__ __forceinline__ void conv_wgrad_body(const ConvWgradArgs& P, float* lds) {
     constexpr int NUNITS = 9 * CI_TILES, NU = (NUNITS + 3) / 4;  // units per wave (round-robin: unit = wave + 4 k)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -489,6 +492,44 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradArgs& P, float* l
             T.fetch(nxt / blocks_per_img, (nxt % blocks_per_img) * R);
             fetch_d(nxt / blocks_per_img, (nxt % blocks_per_img) * R);
         }
+        if constexpr (SPLIT) {
+            for (int pg = 0; pg < ntiles; pg += 2) {   // R W / 16 is even for every supported layer (checked where the op is emitted)
+                float bf[CO_TILES][8];
+#pragma unroll
+                for (int j = 0; j < CO_TILES; ++j)
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) bf[j][s] = d_s[(16 * (pg + (s >> 2)) + 4 * q + (s & 3)) * DS + 16 * j + c];
+                if (wave == 0) {
+#pragma unroll
+                    for (int j = 0; j < CO_TILES; ++j) bs[j] += ((bf[j][0] + bf[j][1]) + (bf[j][2] + bf[j][3])) + ((bf[j][4] + bf[j][5]) + (bf[j][6] + bf[j][7]));
+                }
+                u32x4 bh[CO_TILES], bl[CO_TILES];
+#pragma unroll
+                for (int j = 0; j < CO_TILES; ++j)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) { unsigned h, l; bsplit2(bf[j][2 * w], bf[j][2 * w + 1], h, l); bh[j][w] = h; bl[j][w] = l; }
+                int pb2[2];   // a lane's 4 pixels of a group are consecutive in one image row (W is a multiple of 8): base + i CS
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int p = 16 * (pg + h) + 4 * q;
+                    pb2[h] = ((p / W) * PW + (p % W)) * CS;
+                }
+#pragma unroll
+                for (int k = 0; k < NU; ++k) {
+                    if (wave + 4 * k < NUNITS) {   // wave-uniform
+                        u32x4 ah, al;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) { unsigned h, l; bsplit2(in_s[pb2[w >> 1] + (2 * (w & 1)) * CS + uoff[k]], in_s[pb2[w >> 1] + (2 * (w & 1) + 1) * CS + uoff[k]], h, l); ah[w] = h; al[w] = l; }
+#pragma unroll
+                        for (int j = 0; j < CO_TILES; ++j) acc[k][j] = mfma_bf16(al, bh[j], acc[k][j]);
+#pragma unroll
+                        for (int j = 0; j < CO_TILES; ++j) acc[k][j] = mfma_bf16(ah, bl[j], acc[k][j]);
+#pragma unroll
+                        for (int j = 0; j < CO_TILES; ++j) acc[k][j] = mfma_bf16(ah, bh[j], acc[k][j]);
+                    }
+                }
+            }
+        } else
         for (int pg = 0; pg < ntiles; ++pg) {
             // B fragments: dOut[pixel 16 pg + 4 q + s][16 j + c]   (every wave reads them: they are shared by all units)
             float b[CO_TILES][4];
@@ -543,6 +584,22 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradArgs& P, float* l
     }
 }
 
+__global__ __launch_bounds__(FQL_THREADS, FQL_CWG_WAVES) void fql_conv_wgrad_split_kernel(const ConvWgradArgs* __restrict__ tasks, int ntasks) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const ConvWgradArgs& P = tasks[find_task(tasks, ntasks, blockIdx.x)];
+    const bool even = ((P.R * P.W / 16) & 1) == 0;   // the split loop walks pixel groups in pairs
+    if (P.in_mode == 2) conv_wgrad_body<1, 1, true>(P, lds);   // uint8 first layer: fp32 (staging-bound)
+    else if (!even) {
+        if (P.Ci == 32 && P.Co == 32) conv_wgrad_body<2, 2, false>(P, lds);
+        else if (P.Ci == 16 && P.Co == 32) conv_wgrad_body<1, 2, false>(P, lds);
+        else if (P.Ci == 32 && P.Co == 16) conv_wgrad_body<2, 1, false>(P, lds);
+        else conv_wgrad_body<1, 1, false>(P, lds);
+    }
+    else if (P.Ci == 32 && P.Co == 32) conv_wgrad_body<2, 2, false, true>(P, lds);
+    else if (P.Ci == 16 && P.Co == 32) conv_wgrad_body<1, 2, false, true>(P, lds);
+    else if (P.Ci == 32 && P.Co == 16) conv_wgrad_body<2, 1, false, true>(P, lds);
+    else conv_wgrad_body<1, 1, false, true>(P, lds);
+}
 __global__ __launch_bounds__(FQL_THREADS, FQL_CWG_WAVES) void fql_conv_wgrad_kernel(const ConvWgradArgs* __restrict__ tasks, int ntasks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const ConvWgradArgs& P = tasks[find_task(tasks, ntasks, blockIdx.x)];

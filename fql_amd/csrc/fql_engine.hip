@@ -1832,6 +1832,8 @@ struct fql_engine {
                 break;
             }
             case OP_CONV_WGRAD:
+                if (cfg.precision == 2) FQL_LAUNCH(fql_conv_wgrad_split_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvWgradArgs*)L.table, L.ntasks);
+                else
                 FQL_LAUNCH(fql_conv_wgrad_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvWgradArgs*)L.table, L.ntasks);
                 break;
             case OP_CONV_WRED:
