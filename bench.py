@@ -101,6 +101,7 @@ def profile_kernels(agent, B, reps, split=False):
         names[OP_NAMES.index('fql_chain_kernel')] = 'fql_chain_split_kernel (+ 3 fp32 fql_chain_kernel dgrad launches)'
         names[OP_NAMES.index('fql_conv3x3_kernel')] = 'fql_conv3x3_split_kernel'
         names[OP_NAMES.index('fql_conv_wgrad_kernel')] = 'fql_conv_wgrad_split_kernel'
+        names[OP_NAMES.index('fql_conv3x3_u8_kernel')] = 'fql_conv3x3_u8_split_kernel'
     from fql_amd import _cabi
     lib = _cabi.load()
     f = lib.fql_profile_update
@@ -306,7 +307,7 @@ def main():
         out = {
             'metric': 'FQL gradient-steps/s (batch=256)', 'value': round(steps_per_s * world, 2), 'unit': 'grad-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt * 1e3 / args.steps, 5),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else ('bf16x3 (uint8 first convolution: f32)' if visual else 'bf16x3'), 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else ('bf16x3' if visual else 'bf16x3'), 'data': 'synthetic',
             'config': {'workload': work, 'parallelism': f'dp{world}', 'samples_per_s': round(steps_per_s * world * B, 1)},
             'whole_update': {'flop': flop_per_step, 'wall_us': round(step_us_wall, 3), 'achieved_tflops': round(whole, 3),
                              ('frac_of_fp32_matrix_peak' if peak_tf == FP32_MATRIX_PEAK_TFLOPS else 'frac_of_bf16_matrix_peak_over_3'): round(whole / peak_tf, 4),

@@ -132,7 +132,7 @@ struct ConvTile {
 
 // PIPE: next block's input and this block's epilogue operands are fetched ahead of the MFMA loop (first convolution: uint8 rows,
 // little else to hide the latency); the float layers run without it at a quarter of the registers and 2-3x the occupancy.
-template <int CO_TILES, bool PIPE>
+template <int CO_TILES, bool PIPE, bool SPLITR = false>   // SPLITR (precision = 2, uint8 first layer): fp32 LDS images, fragments split in registers, v_mfma_f32_16x16x16_bf16
 __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 15, q = lane >> 4;
@@ -219,6 +219,25 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
                 for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(in_s + pbase[i] + toff + 16 * g);
 #pragma unroll
                 for (int j = 0; j < CO_TILES; ++j) b[j] = *reinterpret_cast<const f32x4*>(w_s + (16 * j + c) * WS + t * Ci + 16 * g + 4 * q);
+                if constexpr (SPLITR) {
+                    u32x2 ah[2], al[2], bh[CO_TILES], bl[CO_TILES];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) bsplit4(a[i], ah[i], al[i]);
+#pragma unroll
+                    for (int j = 0; j < CO_TILES; ++j) bsplit4(b[j], bh[j], bl[j]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16_k16(al[i], bh[j], acc[i][j]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16_k16(ah[i], bl[j], acc[i][j]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16_k16(ah[i], bh[j], acc[i][j]);
+                } else
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -260,6 +279,11 @@ __global__ __launch_bounds__(FQL_THREADS, FQL_CONV_WAVES) void fql_conv3x3_kerne
     const ConvArgs& P = tasks[find_task(tasks, ntasks, blockIdx.x)];
     if (P.Co == 32) conv_body<2, false>(P, lds);
     else conv_body<1, false>(P, lds);
+}
+__global__ __launch_bounds__(FQL_THREADS, 3) void fql_conv3x3_u8_split_kernel(const ConvArgs* __restrict__ tasks, int ntasks) {   // in_mode 2, precision = 2
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const ConvArgs& P = tasks[find_task(tasks, ntasks, blockIdx.x)];
+    conv_body<1, true, true>(P, lds);
 }
 __global__ __launch_bounds__(FQL_THREADS, 3) void fql_conv3x3_u8_kernel(const ConvArgs* __restrict__ tasks, int ntasks) {   // in_mode 2
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -588,7 +612,7 @@ __global__ __launch_bounds__(FQL_THREADS, FQL_CWG_WAVES) void fql_conv_wgrad_spl
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const ConvWgradArgs& P = tasks[find_task(tasks, ntasks, blockIdx.x)];
     const bool even = ((P.R * P.W / 16) & 1) == 0;   // the split loop walks pixel groups in pairs
-    if (P.in_mode == 2) conv_wgrad_body<1, 1, true>(P, lds);   // uint8 first layer: fp32 (staging-bound)
+    if (P.in_mode == 2) { if (even) conv_wgrad_body<1, 1, true, true>(P, lds); else conv_wgrad_body<1, 1, true>(P, lds); }   // uint8 first layer
     else if (!even) {
         if (P.Ci == 32 && P.Co == 32) conv_wgrad_body<2, 2, false>(P, lds);
         else if (P.Ci == 16 && P.Co == 32) conv_wgrad_body<1, 2, false>(P, lds);

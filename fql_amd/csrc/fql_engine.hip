@@ -1747,6 +1747,7 @@ struct fql_engine {
         else hipLaunchKernelGGL(k, g, b, l, st, __VA_ARGS__);                                     \
     } while (0)
     void issue(const Launch& L, hipStream_t s, int tl) {
+        static const bool u8_split = getenv("FQL_U8_SPLIT") == nullptr || atoi(getenv("FQL_U8_SPLIT")) != 0;
         static const int side_prio = getenv("FQL_SIDE_PRIO") ? atoi(getenv("FQL_SIDE_PRIO")) : 0;
         switch (L.type) {
             case OP_GEMM:
@@ -1817,6 +1818,8 @@ struct fql_engine {
                 FQL_LAUNCH(fql_conv3x3_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
                 break;
             case OP_CONV_U8:
+                if (cfg.precision == 2 && u8_split) FQL_LAUNCH(fql_conv3x3_u8_split_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
+                else
                 FQL_LAUNCH(fql_conv3x3_u8_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
                 break;
             case OP_POOL: {
