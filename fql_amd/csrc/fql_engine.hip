@@ -1110,6 +1110,7 @@ struct fql_engine {
     }
 
     // The same 3-launches-per-step chain on fql_chain_kernel (512-thread workgroups, fragment-major weights, kernarg tasks)
+    bool euler_finish_fused = false;   // set per program build: the head dgrad's prologue finishes the target (GF_A_EULFIN), no OP_EULER_FIN launch
     void emit_euler_chain(Program& pr) {
         const Net& n = nets[NET_BC];
         const int nh = n.nl() - 1, fs = cfg.flow_steps;
@@ -1167,6 +1168,7 @@ struct fql_engine {
                 push(pr, op);
             }
         }
+        if (euler_finish_fused) return;
         Op op{};
         op.type = OP_EULER_FIN;
         const bool from_x = fs == 1;
@@ -2321,6 +2323,12 @@ struct fql_engine {
         // Euler chain through the BC flow (fql.py:155-171): flow_steps sequential forwards
         place("eu", 0, false);
         const int fs = cfg.flow_steps;
+        // FQL_FUSE_EF=1: the last Euler step's target is finished inside the one-step head dgrad's prologue (GF_A_EULFIN: one launch less on the
+        // critical lane).  Built, parity-green (bit-identical target) and measured no faster - bf16x3 3037 -> 3018, fp32 2555 -> 2550 updates/s: the 16
+        // partial loads per element lengthen the prologue of all 256 workgroups by what the launch boundary saved - so it is opt-in.
+        static const bool fuse_ef_env = getenv("FQL_FUSE_EF") != nullptr && atoi(getenv("FQL_FUSE_EF")) != 0;
+        euler_finish_fused = fuse_ef_env && with_grads && getenv("FQL_NO_FUSE_LA") == nullptr && !cfg.actor_layer_norm && !use_pec && fused_euler && use_chain &&
+                             fs > 1 && vp_tiles <= 32;
         if (use_pec) emit_euler_persistent(pr);
         else if (fused_euler && use_chain) emit_euler_chain(pr);
         else if (fused_euler) emit_euler_fused(pr);
@@ -2332,6 +2340,8 @@ struct fql_engine {
         // reports scalars and leaves the critical path (it rides on lane 1): 2083 -> 2130 updates/s.
         static const bool fuse_la_env = getenv("FQL_NO_FUSE_LA") == nullptr;
         const bool fuse_la = with_grads && fuse_la_env && !cfg.actor_layer_norm;
+        Op la_op{};
+        int la_lane = 0;
         {
             Op op{};
             op.type = OP_LOSS_ACTOR;
@@ -2347,7 +2357,8 @@ struct fql_engine {
             }
             const int keep = emit_lane;
             if (fuse_la && !split_build) emit_lane = fill_lane;
-            push(pr, op);
+            if (euler_finish_fused) { la_op = op; la_lane = emit_lane; }   // pushed behind the head dgrad, which now WRITES the target
+            else push(pr, op);
             emit_lane = keep;
         }
         if (with_grads) {
@@ -2381,6 +2392,20 @@ struct fql_engine {
                 d.reads.erase(std::remove(d.reads.begin(), d.reads.end(), (const void*)da), d.reads.end());
                 for (const void* r : {(const void*)p_os.out, (const void*)tgt, (const void*)p_c2[0].dx0, (const void*)p_c2[1].dx0}) d.reads.push_back(r);
                 d.writes.push_back(da);
+                if (euler_finish_fused) {
+                    const Net& nb = nets[NET_BC];
+                    t.flags |= GF_A_EULFIN;
+                    t.aux = Abuf[(fs - 1) & 1]; t.aux2 = Vpart; t.eb = P + nb.layers[nb.nl() - 1].b; t.f1 = 1.0f / (float)fs; t.ln_width = vp_tiles;
+                    d.reads.erase(std::remove(d.reads.begin(), d.reads.end(), (const void*)tgt), d.reads.end());
+                    for (const void* r : {(const void*)Abuf[(fs - 1) & 1], (const void*)Vpart, (const void*)(P + nb.layers[nb.nl() - 1].w)}) d.reads.push_back(r);   // (head bias: WAR against Adam)
+                    d.writes.push_back(tgt);
+                }
+            }
+            if (euler_finish_fused) {   // the metric kernel reads the target the head dgrad has just written
+                const int keep = emit_lane;
+                emit_lane = la_lane;
+                push(pr, la_op);
+                emit_lane = keep;
             }
             // Three lanes: lane 2 is idle by the time the tail runs, so each layer's weight gradient goes there as soon as its dz exists
             // (beside the remaining dgrads of the tail); only the first layer's small one is left behind the last dgrad.

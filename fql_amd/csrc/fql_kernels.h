@@ -107,6 +107,9 @@ enum : int {
     GF_HEAD_PART = 1 << 12, // fused Euler step, part 3: epilogue multiplies the GELU tile into the action head (partials)
     GF_OS_SCATTER = 1 << 13, // one-step head on [next_obs; obs; obs] rows: also write clip(out) into the critic inputs
     GF_A_LOSSACT = 1 << 17,  // A tile = d(actor loss)/d(one-step actions) built in the prologue (agents/fql.py:66-79): no loss kernel on the critical path
+    GF_A_EULFIN = 1 << 15,   // with GF_A_LOSSACT: the distillation target is finished in the same prologue - clip(a_9 + (sum of the last step's head
+                             // partials + head bias) / flow_steps), agents/fql.py:169-170 - instead of by fql_euler_finish_kernel one launch earlier:
+                             // aux = a of the last step [M, i0], aux2 = partials [ln_width][M][i0], eb = head bias, f1 = 1 / flow_steps; evp = target OUT (column tile 0)
     GF_RELUGRAD = 1 << 14,   // epilogue: C = (Zprev > 0) ? acc : 0  (dgrad through the encoder's final ReLU, utils/encoders.py:92)
     GF_LN_PART = 1 << 10,   // gemm64 epilogue: per-row (sum, sum sq) of this 64-column tile -> aux[row][i1 tiles][2]
     GF_C_FRAG = 1 << 18,    // gemm16 epilogue: C (+ bias) stored in accumulator-fragment-major layout [M/4][N][4] (one dwordx4 per lane;
@@ -547,7 +550,18 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
             float g = 0.f;
             if (j < T.i2) {
                 const float ar = ldg(T.ea_in + (size_t)(row0 + r) * T.i0 + j);
-                g = T.f0 * (ar - ldg(T.evp + (size_t)(row0 + r) * T.i0 + j));
+                float tg;
+                if (flags & GF_A_EULFIN) {   // same loads, same summation order as fql_euler_finish_kernel: the target is bit-identical
+                    float pv[32];
+#pragma unroll
+                    for (int tp = 0; tp < 32; ++tp) pv[tp] = ldg(T.aux2 + ((size_t)min(tp, T.ln_width - 1) * T.M + row0 + r) * T.i0 + j);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int tp = 0; tp < 32; ++tp) sum += (tp < T.ln_width) ? pv[tp] : 0.f;
+                    tg = clip1(ldg(T.aux + (size_t)(row0 + r) * T.i0 + j) + (sum + ldg(T.eb + j)) * T.f1);
+                    if (tn == 0) stg(const_cast<float*>(T.evp) + (size_t)(row0 + r) * T.i0 + j, tg);   // the actor-loss metrics read it
+                } else tg = ldg(T.evp + (size_t)(row0 + r) * T.i0 + j);
+                g = T.f0 * (ar - tg);
                 if (ar > -1.0f && ar < 1.0f) {
                     const size_t o = (size_t)(row0 + r) * T.e_ntp + T.i1 + j;
                     g += ldg(T.ew + o) + ldg(T.ew4 + o);
