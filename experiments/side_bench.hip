@@ -2,7 +2,7 @@
 // on 768 rows plus three 256-row passes, [M x 512] x [512 x 512] each = 384 tiles of 32 x 64.  48 launches per hipGraph.
 // Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -o experiments/side_bench experiments/side_bench.hip
 //         (-DFQL_STAMPS: in-kernel phase stamps; never quote that build's run time)
-// argv: [1] flags preset: 0 = bias+gelu+save_z, 1 = + LayerNorm on A and LN partials out (critic layers), 2 = dgrad (W^T) of 4 x 256 rows   [2] tile: 1 = 32x32, 2 = 32x64, 4 = 64x64
+// argv: [3] = 1: precision = 2 (fql_side_split_kernel, bf16x3 tile body)   [1] flags preset: 0 = bias+gelu+save_z, 1 = + LayerNorm on A and LN partials out (critic layers), 2 = dgrad (W^T) of 4 x 256 rows   [2] tile: 1 = 32x32, 2 = 32x64, 4 = 64x64
 #include "../fql_amd/csrc/fql_kernels.h"
 #include <algorithm>
 #include <chrono>
@@ -13,6 +13,8 @@
 int main(int argc, char** argv) {
     const int preset = argc > 1 ? atoi(argv[1]) : 0, shape = argc > 2 ? atoi(argv[2]) : 2;
     const int RI = shape == 4 ? 2 : 1, NJ = shape == 1 ? 1 : 2;
+    const int split = argc > 3 ? atoi(argv[3]) : 0;
+    const int xg = argc > 4 ? atoi(argv[4]) : 0;   // XCD-aware tile order with xg row groups (0 = row-major)
     const int N = 512, K = 512;
     const int Ms[4] = {preset >= 2 ? 256 : 768, 256, 256, 256};
     int flags = GF_BIAS | GF_GELU | GF_SAVE_Z;
@@ -42,7 +44,7 @@ int main(int argc, char** argv) {
             GemmTask t{};
             t.A = (pp ? A1 : A0) + r0 * 512; t.C = (pp ? A0 : A1) + r0 * 512; t.Zout = Z + r0 * 512; t.lda = K; t.ldc = N;
             t.B = W + (size_t)i * K * N; t.ldb = N; t.bias = b + 512; t.M = Ms[i]; t.N = N; t.K = K;
-            t.flags = flags; t.ntn = N / (32 * NJ); t.tile0 = grid; t.tmt = RI; t.wk = NJ;
+            t.flags = flags; t.ntn = N / (32 * NJ); t.tile0 = grid; t.tmt = RI; t.wk = NJ; t.xg = xg;
             t.ln_g = b; t.ln_b = b + 1024; t.ln_width = K; t.ln_xout = XN + r0 * 512; t.ln_stats = stats + r0 * 2;
             t.aux = part + r0 * 32; t.aux2 = part + r0 * 32; t.i0 = K / 32; t.i1 = N / 32;
 #ifdef FQL_STAMPS
@@ -54,12 +56,14 @@ int main(int argc, char** argv) {
         }
     }
     CK(hipMemcpy(tb, h.data(), 8 * sizeof(GemmTask), hipMemcpyHostToDevice));
-    const size_t lds = (size_t)(shape == 4 ? 2 * (64 + 64) * 68 + 256 : shape == 1 ? 2 * 32 * 68 + 2 * 64 * 36 + 128 : 2 * 32 * 68 + 2 * 64 * 68 + 128) * 4;
+    const size_t lds = split ? (size_t)FQL_TILE_SPLIT_LDS_FLOATS(NJ) * 4 : (size_t)(shape == 4 ? 2 * (64 + 64) * 68 + 256 : shape == 1 ? 2 * 32 * 68 + 2 * 64 * 36 + 128 : 2 * 32 * 68 + 2 * 64 * 68 + 128) * 4;
     
     hipGraph_t g; hipGraphExec_t ge;
     CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     for (int i = 0; i < 48; ++i)
         if (shape == 4) hipLaunchKernelGGL(fql_side_big_kernel, dim3(grid), dim3(256), lds, s, (const GemmTask*)(tb + (i % 2) * 4), 4, (const WgradTask*)nullptr, 0,
+                           (const LnBwdTask*)nullptr, 0, grid, grid, (const MiscTask*)nullptr, grid, 0, -1);
+        else if (split) hipLaunchKernelGGL(fql_side_split_kernel, dim3(grid), dim3(256), lds, s, (const GemmTask*)(tb + (i % 2) * 4), 4, (const WgradTask*)nullptr, 0,
                            (const LnBwdTask*)nullptr, 0, grid, grid, (const MiscTask*)nullptr, grid, 0, -1);
         else hipLaunchKernelGGL(fql_side_kernel, dim3(grid), dim3(256), lds, s, (const GemmTask*)(tb + (i % 2) * 4), 4, (const WgradTask*)nullptr, 0,
                            (const LnBwdTask*)nullptr, 0, grid, grid, (const MiscTask*)nullptr, grid, 0, -1);
@@ -71,7 +75,7 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(s));
     const double us = std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t0).count() / (30 * 48);
     const double flop = 2.0 * rows * N * K;
-    printf("side level preset=%d tile=%d grid=%d : %.2f us per launch (%.1f TFLOP/s; MFMA-bound floor %.2f us)\n", preset, shape, grid, us, flop / us / 1e6,
+    printf("side level %s xg=%d preset=%d tile=%d grid=%d : %.2f us per launch (%.1f TFLOP/s; MFMA-bound floor %.2f us)\n", split ? "bf16x3" : "fp32", xg, preset, shape, grid, us, flop / us / 1e6,
            flop / 157.3e6);
 #ifdef FQL_STAMPS
     {

@@ -68,6 +68,7 @@ struct ChainArgs {
     // for the workgroup's 16 rows in LDS (whole rows are there, so the two row statistics need no second pass), then dX = dZ W^T with the
     // row-major kernel as in variant D; no epilogue (the next level's prologue applies its own LayerNorm backward).  A = dY [M, H] or null
     // (scalar head: dY = dq (x) wq), Zprev = GELU'(z), C = dX [M, ldc].  fp32 operands in both precisions.
+    int xg;               // XCD-aware tile order (xcd_tile) with xg row groups; 0 = row-major
     int hw;               // variant E: hidden width of THIS launch's layers (the critic's; the other variants use the BC flow's)
     int tl;               // timeline id (diagnostics build)
     int prio;             // s_setprio level of the chain's waves (they are latency-critical and light: 0.85 us of MFMA per launch)
@@ -142,7 +143,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& P) {
     const int nt = wave & 1, kp = wave >> 1;
     constexpr int variant = V;
     const int ntc = variant == 4 ? P.ncol / 32 : NT;
-    const int tm = blockIdx.x / ntc, tn = blockIdx.x - tm * ntc;
+    int tm = blockIdx.x / ntc, tn = blockIdx.x - tm * ntc;
+    if (P.xg) xcd_tile((int)blockIdx.x, P.M >> 4, ntc, P.xg, tm, tn);
     const int row0 = tm * 16, n0 = tn * 32 + nt * 16;
     tl_enter(P.tl);
     if (P.prio == 3) __builtin_amdgcn_s_setprio(3);
@@ -392,7 +394,8 @@ __global__ __launch_bounds__(FQL_CHAIN_THREADS, (V == 0 ? FQL_CHAIN_SPLIT_WAVES_
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 15, q = lane >> 4;
     const int nt = wave & 1, kp = wave >> 1;
-    const int tm = blockIdx.x / NT, tn = blockIdx.x - tm * NT;
+    int tm = blockIdx.x / NT, tn = blockIdx.x - tm * NT;
+    if (P.xg) xcd_tile((int)blockIdx.x, P.M >> 4, NT, P.xg, tm, tn);
     const int row0 = tm * 16, n0 = tn * 32 + nt * 16;
     constexpr int variant = V;
     tl_enter(P.tl);

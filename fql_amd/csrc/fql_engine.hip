@@ -1427,6 +1427,7 @@ struct fql_engine {
                     // 32 x 64 tiles while a level is a latency chain (B = 256: 1.5 workgroups per CU), 64 x 64 once a task alone
                     // brings >= 128 of them (M >= 1024: +2 % at B = 1024)
                     static const int ri_env = getenv("FQL_G64_RI") ? atoi(getenv("FQL_G64_RI")) : 0;
+                    static const bool xcd_order = getenv("FQL_NO_XCD") == nullptr;
                     int ri = 1;
                     int tile = 0;
                     std::vector<GemmTask> tg;
@@ -1458,6 +1459,20 @@ struct fql_engine {
                         t.tmt = ri_t;
                         t.wk = ri_t == 2 ? 2 : nj;          // MFMA column tiles per wave: tile = 32 x (32 wk)
                         t.ntn = t.N / (32 * t.wk); t.tile0 = tile;
+                        t.xg = 0;
+                        if (ri_t == 1 && xcd_order && tile % 8 == 0) {   // XCD-aware tile order: gm x gn = 8 blocks of the tile grid, fewest panel fetches
+                            const int ntm = t.M / 32;
+                            // gm row groups x gn column groups: an A row panel is fetched by gn XCDs, a B column panel by gm -> fewest panel bytes
+                            // (FQL_XCD_GM forces gm; measured on the whole update: the rule's choice 3075, forced 4: 3001-3061, 8: 2864-3026, 1: 2967-3040, off: 3025)
+                            static const int gm_env = getenv("FQL_XCD_GM") ? atoi(getenv("FQL_XCD_GM")) : 0;
+                            double best = 1e30;
+                            for (int gm : {1, 2, 4, 8}) {
+                                const int gn = 8 / gm;
+                                if (ntm % gm || t.ntn % gn || (gm_env && gm != gm_env)) continue;
+                                const double cost = (double)gn * t.M + (double)gm * t.N;
+                                if (cost < best) { best = cost; t.xg = gm; }
+                            }
+                        }
                         tile += (t.M / (32 * ri_t)) * t.ntn;
                         tg.push_back(t);
                     }
@@ -1851,6 +1866,21 @@ struct fql_engine {
             }
             case OP_CHAIN: {
                 ChainArgs ca = L.op.chain; ca.tl = tl;
+                {   // XCD-aware tile order of the chain launches (16-row tiles x 32-column tiles)
+                    static const bool xcd_order = getenv("FQL_NO_XCD") == nullptr;
+                    const int ntm = ca.M / 16, ntn = (ca.variant == 4 ? ca.ncol : cfg.actor_hidden[0]) / 32;
+                    ca.xg = 0;
+                    if (xcd_order && ca.variant != 4) {
+                        static const int gm_env = getenv("FQL_XCD_GM_CHAIN") ? atoi(getenv("FQL_XCD_GM_CHAIN")) : 0;
+                        double best = 1e30;
+                        for (int gm : {1, 2, 4, 8}) {
+                            const int gn = 8 / gm;
+                            if (ntm % gm || ntn % gn || (gm_env && gm != gm_env)) continue;
+                            const double cost = (double)gn * ca.M + (double)gm * cfg.actor_hidden[0];
+                            if (cost < best) { best = cost; ca.xg = gm; }
+                        }
+                    }
+                }
                 if (ca.variant == 4) {   // fused LayerNorm-backward + dgrad level of the critic's Q-gradient chain (fp32 operands in both precisions)
                     const dim3 g4((ca.M / 16) * (ca.ncol / 32), L.chain_pair ? 2 : 1);
                     if (L.chain_pair) {

@@ -23,6 +23,19 @@ __device__ __forceinline__ void stg4(float* p, f32x4 v) { *(FQL_GAS f32x4*)p = v
 
 #define FQL_THREADS 256
 
+// XCD-aware tile order (cdna_hip_programming.md T1): workgroups are dealt round-robin over the 8 XCDs, each with a private L2 that is cold after
+// every kernel boundary, so workgroups b, b + 8, ... share an L2.  Handing each XCD a compact (ntm / gm) x (ntn / gn) block of a task's tile grid
+// (gm gn = 8) instead of every 8th tile makes the tiles that share an A row panel or a B column panel fetch it from the Infinity Cache once per
+// XCD that needs it (gn + gm panel fetches instead of 8 + 8).  `local` = tile index inside the task, whose first workgroup is a multiple of 8.
+// Placement is a speed matter only: results do not depend on which workgroup computes which tile.
+__device__ __forceinline__ void xcd_tile(int local, int ntm, int ntn, int gm, int& tm, int& tn) {
+    const int gn = 8 / gm, x = local & 7, j = local >> 3;
+    const int bn = ntn / gn, bm = ntm / gm;
+    const int jm = j / bn;
+    tm = (x / gn) * bm + jm;
+    tn = (x - (x / gn) * gn) * bn + (j - jm * bn);
+}
+
 // ------------------------------------------------------------------------------------------------
 // precision = 2 ("bf16x3", SURVEY 8b config key `precision`): an fp32 operand x is split into two bf16 values
 //   hi = bf16(x), lo = bf16(x - hi)            (both round-to-nearest-even; x - hi is exact in fp32)
@@ -147,6 +160,7 @@ struct GemmTask {
     float* evp;          // head partials [ntiles][M][ap]: read by A_EULER0 (null on step 0), written by HEAD_PART
     const float* eb;     // head bias [ap]
     int e_ntp;           // number of partial tiles to fold (A_EULER0)
+    int xg;              // 32-row tile bodies: XCD-aware tile order with gm = xg row groups (xcd_tile); 0 = row-major tile order
 #ifdef FQL_STAMPS
     unsigned long long* stamps64;   // diagnostics build: gemm64 phase stamps [workgroup][8]
 #endif
@@ -1046,7 +1060,8 @@ __device__ __forceinline__ void gemm32_body(const GemmTask& T, float* lds) {
     float* Bs = lds + 2 * 32 * G64_S;             // [2][BROWS][BS]
     float* part = Bs + 2 * BROWS * BS;            // [2 column halves][32][2] LN partial sums of the epilogue
     const int local = (int)blockIdx.x - T.tile0;
-    const int tm = local / T.ntn, tn = local - tm * T.ntn;
+    int tm = local / T.ntn, tn = local - tm * T.ntn;
+    if (T.xg) xcd_tile(local, T.M >> 5, T.ntn, T.xg, tm, tn);
     const int row0 = tm * 32, n0 = tn * TN;
     const int K = T.K;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1251,7 +1266,8 @@ __device__ __forceinline__ void gemm32s_body(const GemmTask& T, float* lds_f) {
     unsigned* Bs = As + 4 * APL;                          // [2 buffers][hi, lo][BPL]
     float* part = reinterpret_cast<float*>(Bs + 4 * BPL); // [2 column halves][32][2] LN partial sums of the epilogue
     const int local = (int)blockIdx.x - T.tile0;
-    const int tm = local / T.ntn, tn = local - tm * T.ntn;
+    int tm = local / T.ntn, tn = local - tm * T.ntn;
+    if (T.xg) xcd_tile(local, T.M >> 5, T.ntn, T.xg, tm, tn);
     const int row0 = tm * 32, n0 = tn * TN;
     const int K = T.K;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1260,6 +1276,14 @@ __device__ __forceinline__ void gemm32s_body(const GemmTask& T, float* lds_f) {
     const int flags = T.flags;
     const bool a_ln = (flags & GF_A_LN) != 0;
     const bool ln_wr = (flags & GF_LN_WRITE) && tn == 0;
+#ifdef FQL_STAMPS
+    unsigned long long stamp[8];
+    int nst = 0;
+#define SSTAMP() do { __builtin_amdgcn_s_waitcnt(0); stamp[nst++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SSTAMP() do {} while (0)
+#endif
+    SSTAMP();
     const int sr = tid >> 4, sc4 = tid & 15;      // A staging: rows sr, sr + 16; float4 column sc4 (k = 4 sc4 .. 4 sc4 + 3)
     const int br0 = (transb || NJ == 2) ? sr : (tid >> 3), brs = (transb || NJ == 2) ? 16 : 32;
     const int bc4 = (transb || NJ == 2) ? sc4 : (tid & 7);
@@ -1290,6 +1314,7 @@ __device__ __forceinline__ void gemm32s_body(const GemmTask& T, float* lds_f) {
             if (ln_wr && sc4 == 0) { const int row = row0 + sr + 16 * i; stg(T.ln_stats + 2 * row, mean[i]); stg(T.ln_stats + 2 * row + 1, rstd[i]); }
         }
     }
+    SSTAMP();   // [1] LayerNorm statistics folded
     // word offset, inside a 32-word [row][64 k] row, of the 4 k values a staging thread owns: 4-k block t = sc4 -> MFMA step
     // kp = t >> 3, owner quarter q = t & 3, half h = (t >> 2) & 1 of that lane's 8 values; slot 4 kp + q is swizzled per row
     const int st_slot = 4 * (sc4 >> 3) + (sc4 & 3), st_h = (sc4 >> 2) & 1;
@@ -1380,6 +1405,7 @@ __device__ __forceinline__ void gemm32s_body(const GemmTask& T, float* lds_f) {
     store_chunk(ra0, rb0, lg0, lb0, 0, 0);
     if (nchunks > 2) load_chunk(ra0, rb0, lg0, lb0, 128);
     __syncthreads();
+    SSTAMP();   // [2] first chunk staged
     for (int ch = 0; ch < nchunks; ch += 2) {
         compute(0);
         if (ch + 1 < nchunks) store_chunk(ra1, rb1, lg1, lb1, 64 * (ch + 1), 1);
@@ -1393,6 +1419,7 @@ __device__ __forceinline__ void gemm32s_body(const GemmTask& T, float* lds_f) {
         }
     }
 
+    SSTAMP();   // [3] K loop done
     // ---- epilogue (that of gemm32_body). C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
     float s1[4], s2[4];
 #pragma unroll
@@ -1439,6 +1466,13 @@ __device__ __forceinline__ void gemm32s_body(const GemmTask& T, float* lds_f) {
             stg(pp + 1, part[tid * 2 + 1] + part[(32 + tid) * 2 + 1]);
         }
     }
+#ifdef FQL_STAMPS
+    SSTAMP();   // [4] epilogue stored
+    if (tid == 0 && T.stamps64) {
+        unsigned long long* d = T.stamps64 + (size_t)blockIdx.x * 8;
+        for (int i = 0; i < nst; ++i) d[i] = stamp[i];
+    }
+#endif
 }
 #define FQL_TILE_SPLIT_LDS_FLOATS(NJ) (4 * 32 * 32 + 4 * 32 * 32 * (NJ) + 128)
 
