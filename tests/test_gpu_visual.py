@@ -189,7 +189,8 @@ def test_visual_begin_end_halves_and_checkpoint_round_trip(tmp_path):
     assert i1 == i2
 
 
-def test_visual_full_size_is_deterministic_and_consistent():
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_visual_full_size_is_deterministic_and_consistent(precision):
     """BASELINE configs[4] at full size (64x64x9 uint8, B=256, impala_small, hidden 512x4): the oracle would take minutes
     here, so size-independent properties instead: two engines on the same bytes agree bitwise (no atomics anywhere),
     total_loss == the loss terms update() reports for the same step, and the frames gather with identity crop reproduces an
@@ -198,7 +199,7 @@ def test_visual_full_size_is_deterministic_and_consistent():
     from oracle import encoder_oracle as E
     B, ad, fs, n = 256, 5, 3, 600
     cfg = fql_amd.get_config()
-    cfg.update(encoder='impala_small', alpha=300.0, batch_size=B)
+    cfg.update(encoder='impala_small', alpha=300.0, batch_size=B, precision=precision)
     rng = np.random.default_rng(21)
     frames = rng.integers(0, 256, size=(n, 64, 64, 3), dtype=np.uint8)
     nxt = rng.integers(0, 256, size=(n, 64, 64, 3), dtype=np.uint8)
@@ -224,7 +225,10 @@ def test_visual_full_size_is_deterministic_and_consistent():
     assert ia == ib
     assert all(np.isfinite(v) for v in ia.values())
     for k in ('critic/critic_loss', 'actor/actor_loss', 'actor/bc_flow_loss', 'actor/distill_loss', 'actor/q_loss', 'actor/mse'):
-        assert itl[k] == ib[k], k                                            # same kernels, same inputs: bitwise
+        if precision == 'fp32':
+            assert itl[k] == ib[k], k                                        # same kernels, same inputs: bitwise
+        else:   # the forward-only program may leave a product on the 16-row fp32 kernel that the update program runs on a split tile
+            assert abs(itl[k] - ib[k]) <= 2e-4 * max(1.0, abs(ib[k])), (k, itl[k], ib[k])
     assert abs(loss - (ib['critic/critic_loss'] + ib['actor/actor_loss'])) <= 1e-5 * abs(loss)
     pa, pb = leaf_dict(a.get_params()), leaf_dict(b.get_params())
     for k in pa:
