@@ -7,6 +7,9 @@
 #ifndef FQL_CONV_WAVES
 #define FQL_CONV_WAVES 3   // min waves per SIMD of the float convolution kernel (116 registers: up to 4)
 #endif
+#ifndef FQL_CONV_NS
+#define FQL_CONV_NS 3   // float4 per thread of the input rows requested in one round, the rest in a rolled loop (6 cover every supported layer but cost a workgroup per CU of registers: measured slower)
+#endif
 #ifndef FQL_CWG_WAVES
 #define FQL_CWG_WAVES 3   // min waves per SIMD of the convolution weight-gradient kernel: 165 registers, three workgroups per CU
 #endif
@@ -36,6 +39,9 @@ struct ConvArgs {
     int transposed;       // 0 forward, 1 data gradient (informational: Wl is the matching layout)
     int R;                // image rows per workgroup
     int tile0, nwg;       // first workgroup of this task inside a shared launch, and how many it has
+#ifdef FQL_STAMPS
+    unsigned long long* stamps;   // diagnostics build (experiments/conv_bench.hip): [workgroup][8] wall-clock stamps of the first row block
+#endif
 };
 
 // Input rows y0-1 .. y0+R of image n (zero halo) -> LDS [(R+2)][(W+2)][Ci+4], in two halves so the global loads of the NEXT
@@ -87,11 +93,13 @@ struct ConvTile {
         y0 = y0_;
         if (is_u8) {
             const int dpr = (W * Ci_real) >> 2, total = (R + 2) * dpr;   // dwords per image row
+            const FastDiv fdpr(dpr);
             const unsigned* src = (const unsigned*)((const unsigned char*)in + (size_t)n * H * W * Ci_real);
 #pragma unroll
             for (int i = 0; i < NU8; ++i) {
                 const int e = min(tid + i * FQL_THREADS, total - 1);
-                const int rr = e / dpr, cd = e - rr * dpr;
+                int rr, cd;
+                fdpr.divmod(e, rr, cd);
                 const int yy = min(max(y0 + rr - 1, 0), H - 1);
                 prew[i] = __builtin_nontemporal_load(src + (size_t)yy * dpr + cd);
             }
@@ -107,11 +115,12 @@ struct ConvTile {
     __device__ __forceinline__ void commit() {
         if (is_u8) {
             const int dpr = (W * Ci_real) >> 2, total = (R + 2) * dpr;
+            const FastDiv fdpr(dpr);
 #pragma unroll
             for (int i = 0; i < NU8; ++i) {
                 const int e = tid + i * FQL_THREADS;
                 if (e >= total) continue;
-                const int yy = y0 + e / dpr - 1;
+                const int yy = y0 + fdpr.div(e) - 1;
                 const bool ok = yy >= 0 && yy < H;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) in_s[u8off[i][k]] = ok ? (float)((prew[i] >> (8 * k)) & 255u) * (1.0f / 255.0f) : 0.f;
@@ -142,13 +151,24 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
     float* w_s = lds + (R + 2) * PW * CS;              // [Co][WS]
     const int blocks_per_img = H / R;
     const int nblocks = P.N * blocks_per_img;
+    const FastDiv fW(W), fPW(PW), fC4(Ci >> 2), fBPI(blocks_per_img);
     const int wg = (int)blockIdx.x - P.tile0, nwg = P.nwg;   // this task's workgroups walk its row blocks with stride nwg
+#ifdef FQL_STAMPS
+    unsigned long long stamp[8];
+    int nst = 0;
+#define VSTAMP() do { if (nst < 8) { __builtin_amdgcn_s_waitcnt(0); stamp[nst++] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define VSTAMP() do {} while (0)
+#endif
+    VSTAMP();   // [0] entry
     ConvTile T;
     T.in = P.in; T.in_s = in_s; T.H = H; T.W = W; T.Ci = Ci; T.Ci_real = P.Ci_real; T.R = R; T.CS = CS; T.PW = PW; T.tid = tid;
     T.in_mode = PIPE ? 2 : P.in_mode; T.is_u8 = PIPE;   // the pipelined body is the uint8 first layer only: a constant here lets the float staging path (and its registers) fold away
     if constexpr (PIPE) {
         T.init();
-        T.fetch(wg / blocks_per_img, (wg % blocks_per_img) * R);
+        int wn, wb;
+        fBPI.divmod(wg, wn, wb);
+        T.fetch(wn, wb * R);
     }
 
     // ---- weights -> LDS ([out channel][k]); staged once, the workgroup then walks its share of the row blocks
@@ -156,13 +176,16 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
         const int total = (Co * WS) >> 2;   // straight 16-byte copy: the layout was prepared by fql_conv_wprep_kernel
         for (int e = tid; e < total; e += FQL_THREADS) *reinterpret_cast<f32x4*>(w_s + 4 * e) = ldg4(P.Wl + 4 * e);
     }
+    VSTAMP();   // [1] weights copied to LDS (stores issued)
     const int ntiles = R * W / 16;
     int pbase[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int t = min(wave + 4 * i, ntiles - 1);  // clamped: results of a duplicate tile are discarded
         const int p = 16 * t + c;
-        pbase[i] = ((p / W) * PW + (p % W)) * CS + 4 * q;
+        int py, pxm;
+        fW.divmod(p, py, pxm);
+        pbase[i] = (py * PW + pxm) * CS + 4 * q;
     }
     float bv[CO_TILES];
 #pragma unroll
@@ -170,15 +193,48 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
     const int ngroups = Ci >> 4;
 
     for (int blk = wg; blk < nblocks; blk += nwg) {
-        const int n = blk / blocks_per_img, y0 = (blk % blocks_per_img) * R;
+        int n, y0;
+        fBPI.divmod(blk, n, y0);
+        y0 *= R;
         __syncthreads();  // the previous block's fragments are consumed (first pass: the zero fill / weights are in place)
         if constexpr (PIPE) {
             T.commit();
-        } else {   // rolled staging loop: few registers, latency hidden by the other resident workgroups
+        } else {
+            // staging: the first FQL_CONV_NS float4 of every thread are requested TOGETHER (clamped addresses, zeroed on commit) - one load round trip
+            // instead of one per element: in-kernel stamps (experiments/conv_bench_st) showed the rolled loop at 4.1 us of a workgroup's 7.8 us, the MFMA
+            // loop at 1.65 - then a rolled loop for what is left (none for the supported layers)
             const float* src = (const float*)P.in + (size_t)n * H * W * Ci;
             const int c4 = Ci >> 2, total = (R + 2) * PW * c4;
-            for (int e = tid; e < total; e += FQL_THREADS) {
-                const int cc = e % c4, px = e / c4, xx = px % PW - 1, yy = y0 + px / PW - 1;
+            {
+                f32x4 sv[FQL_CONV_NS];
+                int so[FQL_CONV_NS];
+#pragma unroll
+                for (int i = 0; i < FQL_CONV_NS; ++i) {
+                    const int e = tid + i * FQL_THREADS, ec = min(e, total - 1);
+                    int cc, px, prow, xx;
+                    fC4.divmod(ec, px, cc);
+                    fPW.divmod(px, prow, xx);
+                    xx -= 1;
+                    const int yy = y0 + prow - 1;
+                    const bool inb = e < total && xx >= 0 && xx < W && yy >= 0 && yy < H;
+                    sv[i] = ldg4(src + ((size_t)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)) * Ci + 4 * cc);
+                    so[i] = e < total ? ((px * CS + 4 * cc) << 1) | (inb ? 1 : 0) : -1;
+                }
+#pragma unroll
+                for (int i = 0; i < FQL_CONV_NS; ++i) {
+                    if (so[i] < 0) continue;
+                    f32x4 v = sv[i];
+                    if (P.in_mode == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                    if (!(so[i] & 1)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4*>(in_s + (so[i] >> 1)) = v;
+                }
+            }
+            for (int e = tid + FQL_CONV_NS * FQL_THREADS; e < total; e += FQL_THREADS) {
+                int cc, px, prow, xx;
+                fC4.divmod(e, px, cc);
+                fPW.divmod(px, prow, xx);
+                xx -= 1;
+                const int yy = y0 + prow - 1;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
                     v = ldg4(src + ((size_t)yy * W + xx) * Ci + 4 * cc);
@@ -188,8 +244,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
             }
         }
         __syncthreads();
+        VSTAMP();   // [2] input rows staged
         const int nxt = blk + nwg;
-        if constexpr (PIPE) { if (nxt < nblocks) T.fetch(nxt / blocks_per_img, (nxt % blocks_per_img) * R); }
+        if constexpr (PIPE) { if (nxt < nblocks) { int nn, nb; fBPI.divmod(nxt, nn, nb); T.fetch(nn, nb * R); } }
         // epilogue operands of this block: issued now, consumed after the MFMA loop
         float mk[2][CO_TILES][4], ad[2][CO_TILES][4];
         if (PIPE)
@@ -200,8 +257,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
             for (int j = 0; j < CO_TILES; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int p = 16 * t + 4 * q + r;
-                    const size_t o = (((size_t)n * H + y0 + p / W) * W + (p % W)) * Co + 16 * j + c;
+                    int py, pxm;
+                    fW.divmod(16 * t + 4 * q, py, pxm);   // a lane's four pixels are consecutive in one image row (W is a multiple of 4)
+                    const size_t o = (((size_t)n * H + y0 + py) * W + pxm + r) * Co + 16 * j + c;
                     mk[i][j][r] = P.mask ? ldg(P.mask + o) : 1.f;
                     ad[i][j][r] = P.add ? ldg(P.add + o) : 0.f;
                 }
@@ -246,6 +304,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
                         for (int j = 0; j < CO_TILES; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
             }
         }
+        VSTAMP();   // [3] MFMA loop done
         // ---- epilogue.  C layout: col = lane & 15 (channel), row = 4 q + r (pixel of the tile)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -255,8 +314,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
             for (int j = 0; j < CO_TILES; ++j) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int p = 16 * t + 4 * q + r;
-                    const size_t o = (((size_t)n * H + y0 + p / W) * W + (p % W)) * Co + 16 * j + c;
+                    int py, pxm;
+                    fW.divmod(16 * t + 4 * q, py, pxm);
+                    const size_t o = (((size_t)n * H + y0 + py) * W + pxm + r) * Co + 16 * j + c;
                     float v = acc[i][j][r] + bv[j];
                     if (PIPE) {
                         v = (mk[i][j][r] > 0.f) ? v : 0.f;
@@ -270,7 +330,14 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
                 }
             }
         }
+        VSTAMP();   // [4] epilogue stored
     }  // row blocks
+#ifdef FQL_STAMPS
+    if (tid == 0 && P.stamps) {
+        unsigned long long* d = P.stamps + (size_t)blockIdx.x * 8;
+        for (int i = 0; i < nst; ++i) d[i] = stamp[i];
+    }
+#endif
 }
 
 // One launch = every convolution of one scheduling level (e.g. the same layer of the four encoder passes): task table in HBM.
@@ -314,6 +381,7 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& P, float* lds_f)
     unsigned* w_l = w_h + WPL;
     const int blocks_per_img = H / R;
     const int nblocks = P.N * blocks_per_img;
+    const FastDiv fW(W), fPW(PW), fBPI(blocks_per_img);
     const int wg = (int)blockIdx.x - P.tile0, nwg = P.nwg;
     {   // weights -> LDS: hi plane then lo plane, a straight 16-byte copy (the padding words are zero in the copy)
         const int total = (2 * WPL) >> 2;
@@ -330,7 +398,9 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& P, float* lds_f)
     for (int i = 0; i < 2; ++i) {
         const int t = min(wave + 4 * i, ntiles - 1);  // clamped: results of a duplicate tile are discarded
         const int p = 16 * t + c;
-        pbase[i] = ((p / W) * PW + (p % W)) * PSW + KW * q;
+        int py, pxm;
+        fW.divmod(p, py, pxm);
+        pbase[i] = (py * PW + pxm) * PSW + KW * q;
     }
     float bv[CO_TILES];
 #pragma unroll
@@ -340,14 +410,47 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& P, float* lds_f)
     for (int j = 0; j < CO_TILES; ++j) wbase[j] = (16 * j + c) * WSW + KW * q;
 
     for (int blk = wg; blk < nblocks; blk += nwg) {
-        const int n = blk / blocks_per_img, y0 = (blk % blocks_per_img) * R;
+        int n, y0;
+        fBPI.divmod(blk, n, y0);
+        y0 *= R;
         __syncthreads();
         {
             const float* src = (const float*)P.in + (size_t)n * H * W * CI;
             constexpr int c4 = CI >> 2;
             const int total = (R + 2) * PW * c4;
-            for (int e = tid; e < total; e += FQL_THREADS) {
-                const int cc = e % c4, px = e / c4, xx = px % PW - 1, yy = y0 + px / PW - 1;
+            {   // one load round trip for the first FQL_CONV_NS float4 of every thread (see conv_body)
+                f32x4 sv[FQL_CONV_NS];
+                int so[FQL_CONV_NS];
+#pragma unroll
+                for (int i = 0; i < FQL_CONV_NS; ++i) {
+                    const int e = tid + i * FQL_THREADS, ec = min(e, total - 1);
+                    const int cc = ec % c4, px = ec / c4;   // c4 is a compile-time power of two
+                    int prow, xx;
+                    fPW.divmod(px, prow, xx);
+                    xx -= 1;
+                    const int yy = y0 + prow - 1;
+                    const bool inb = e < total && xx >= 0 && xx < W && yy >= 0 && yy < H;
+                    sv[i] = ldg4(src + ((size_t)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)) * CI + 4 * cc);
+                    so[i] = e < total ? ((px * PSW + 2 * cc) << 1) | (inb ? 1 : 0) : -1;
+                }
+#pragma unroll
+                for (int i = 0; i < FQL_CONV_NS; ++i) {
+                    if (so[i] < 0) continue;
+                    f32x4 v = sv[i];
+                    if (P.in_mode == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                    if (!(so[i] & 1)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    u32x2 hi, lo;
+                    bsplit4(v, hi, lo);
+                    *reinterpret_cast<u32x2*>(in_h + (so[i] >> 1)) = hi;
+                    *reinterpret_cast<u32x2*>(in_l + (so[i] >> 1)) = lo;
+                }
+            }
+            for (int e = tid + FQL_CONV_NS * FQL_THREADS; e < total; e += FQL_THREADS) {
+                const int cc = e % c4, px = e / c4;
+                int prow, xx;
+                fPW.divmod(px, prow, xx);
+                xx -= 1;
+                const int yy = y0 + prow - 1;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
                     v = ldg4(src + ((size_t)yy * W + xx) * CI + 4 * cc);
@@ -414,8 +517,9 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& P, float* lds_f)
             for (int j = 0; j < CO_TILES; ++j) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int p = 16 * t + 4 * q + r;
-                    const size_t o = (((size_t)n * H + y0 + p / W) * W + (p % W)) * Co + 16 * j + c;
+                    int py, pxm;
+                    fW.divmod(16 * t + 4 * q, py, pxm);   // a lane's four pixels are consecutive in one image row
+                    const size_t o = (((size_t)n * H + y0 + py) * W + pxm + r) * Co + 16 * j + c;
                     float v = acc[i][j][r] + bv[j];
                     if (P.mask) v = (ldg(P.mask + o) > 0.f) ? v : 0.f;
                     if (P.add) v += ldg(P.add + o);
@@ -470,26 +574,31 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradArgs& P, float* l
     constexpr int ND = 4;   // dOut float4 per thread: R W Co / 4 / 256 <= 128 * 8 / 256
     f32x4 dpre[ND];
     const int dc4 = Co >> 2, dtotal = R * W * dc4;
+    const FastDiv fW(W), fDC4(dc4), fBPI(blocks_per_img);
     auto fetch_d = [&](int n, int y0) {
         const float* src = P.dout + ((size_t)n * H + y0) * W * Co;
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             const int e = min(tid + i * FQL_THREADS, dtotal - 1);
-            dpre[i] = ldg4(src + (size_t)(e / dc4) * Co + 4 * (e % dc4));
+            int ep, ec;
+            fDC4.divmod(e, ep, ec);
+            dpre[i] = ldg4(src + (size_t)ep * Co + 4 * ec);
         }
     };
     auto commit_d = [&]() {
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             const int e = tid + i * FQL_THREADS;
-            if (e < dtotal) *reinterpret_cast<f32x4*>(d_s + (e / dc4) * DS + 4 * (e % dc4)) = dpre[i];
+            if (e < dtotal) { int ep, ec; fDC4.divmod(e, ep, ec); *reinterpret_cast<f32x4*>(d_s + ep * DS + 4 * ec) = dpre[i]; }
         }
     };
     const int wg = (int)blockIdx.x - P.tile0, nwg = P.nwg;
     T.init();
     if (wg < P.nblocks) {
-        T.fetch(wg / blocks_per_img, (wg % blocks_per_img) * R);
-        fetch_d(wg / blocks_per_img, (wg % blocks_per_img) * R);
+        int wn, wb;
+        fBPI.divmod(wg, wn, wb);
+        T.fetch(wn, wb * R);
+        fetch_d(wn, wb * R);
     }
     f32x4 acc[NU][CO_TILES];
 #pragma unroll
@@ -513,8 +622,10 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradArgs& P, float* l
         __syncthreads();
         const int nxt = blk + nwg;
         if (nxt < P.nblocks) {
-            T.fetch(nxt / blocks_per_img, (nxt % blocks_per_img) * R);
-            fetch_d(nxt / blocks_per_img, (nxt % blocks_per_img) * R);
+            int nn, nb;
+            fBPI.divmod(nxt, nn, nb);
+            T.fetch(nn, nb * R);
+            fetch_d(nn, nb * R);
         }
         if constexpr (SPLIT) {
             for (int pg = 0; pg < ntiles; pg += 2) {   // R W / 16 is even for every supported layer (checked where the op is emitted)
@@ -535,8 +646,9 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradArgs& P, float* l
                 int pb2[2];   // a lane's 4 pixels of a group are consecutive in one image row (W is a multiple of 8): base + i CS
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const int p = 16 * (pg + h) + 4 * q;
-                    pb2[h] = ((p / W) * PW + (p % W)) * CS;
+                    int py, pxm;
+                    fW.divmod(16 * (pg + h) + 4 * q, py, pxm);
+                    pb2[h] = (py * PW + pxm) * CS;
                 }
 #pragma unroll
                 for (int k = 0; k < NU; ++k) {
@@ -565,11 +677,12 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradArgs& P, float* l
 #pragma unroll
                 for (int j = 0; j < CO_TILES; ++j) bs[j] += (b[j][0] + b[j][1]) + (b[j][2] + b[j][3]);
             }
-            int pb[4];
+            int pb[4];   // a lane's four pixels are consecutive in one image row (W is a multiple of 4)
+            {
+                int py, pxm;
+                fW.divmod(16 * pg + 4 * q, py, pxm);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int p = 16 * pg + 4 * q + s;
-                pb[s] = ((p / W) * PW + (p % W)) * CS;
+                for (int s = 0; s < 4; ++s) pb[s] = (py * PW + pxm + s) * CS;
             }
 #pragma unroll
             for (int k = 0; k < NU; ++k) {
@@ -681,13 +794,13 @@ struct PoolArgs {
 };
 __global__ __launch_bounds__(FQL_THREADS) void fql_maxpool_kernel(const PoolArgs P) {
     const int c4 = P.C >> 2, Ho = P.H >> 1, Wo = P.W >> 1;
-    const size_t e = (size_t)blockIdx.x * FQL_THREADS + threadIdx.x;
-    if (e >= (size_t)P.N * Ho * Wo * c4) return;
-    const int cc = (int)(e % c4);
-    size_t r = e / c4;
-    const int ox = (int)(r % Wo); r /= Wo;
-    const int oy = (int)(r % Ho);
-    const int n = (int)(r / Ho);
+    const size_t e64 = (size_t)blockIdx.x * FQL_THREADS + threadIdx.x;
+    if (e64 >= (size_t)P.N * Ho * Wo * c4) return;   // (< 2^31 elements: checked where the op is emitted)
+    const FastDiv fC4(c4), fWo(Wo), fHo(Ho);
+    int cc, r, ox, oy, n;
+    fC4.divmod((int)e64, r, cc);
+    fWo.divmod(r, r, ox);
+    fHo.divmod(r, n, oy);
     f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     int arg[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -714,13 +827,13 @@ struct PoolBwdArgs {
 };
 __global__ __launch_bounds__(FQL_THREADS) void fql_maxpool_bwd_kernel(const PoolBwdArgs P) {
     const int c4 = P.C >> 2, Ho = P.H >> 1, Wo = P.W >> 1;
-    const size_t e = (size_t)blockIdx.x * FQL_THREADS + threadIdx.x;
-    if (e >= (size_t)P.N * P.H * P.W * c4) return;
-    const int cc = (int)(e % c4);
-    size_t r = e / c4;
-    const int x = (int)(r % P.W); r /= P.W;
-    const int y = (int)(r % P.H);
-    const int n = (int)(r / P.H);
+    const size_t e64 = (size_t)blockIdx.x * FQL_THREADS + threadIdx.x;
+    if (e64 >= (size_t)P.N * P.H * P.W * c4) return;   // (< 2^31 elements)
+    const FastDiv fC4(c4), fW(P.W), fH(P.H);
+    int cc, r, x, y, n;
+    fC4.divmod((int)e64, r, cc);
+    fW.divmod(r, r, x);
+    fH.divmod(r, n, y);
     f32x4 g = {0.f, 0.f, 0.f, 0.f};
     // windows oy with 2 oy <= y <= 2 oy + 2
     for (int oy = max(0, (y - 1) >> 1); oy <= min(Ho - 1, y >> 1); ++oy)

@@ -23,6 +23,17 @@ __device__ __forceinline__ void stg4(float* p, f32x4 v) { *(FQL_GAS f32x4*)p = v
 
 #define FQL_THREADS 256
 
+// Division of a small non-negative int by a kernel-uniform divisor without the ~40-instruction integer division sequence (100+ for 64-bit indices):
+// q = umulhi(x, ceil(2^32 / d)), exact whenever x d < 2^32.  The convolution / pooling kernels index pixels through W, W + 2, channel quads ...: their
+// epilogues and staging loops were bound by these divisions (experiments/conv_bench_st: 4.1 us of staging per 7.8 us workgroup against 1.65 us of MFMA).
+struct FastDiv {
+    unsigned m;
+    int d;
+    __device__ __forceinline__ explicit FastDiv(int dd) : m(dd > 1 ? 0xFFFFFFFFu / (unsigned)dd + 1u : 0u), d(dd) {}
+    __device__ __forceinline__ int div(int x) const { return d == 1 ? x : (int)__umulhi((unsigned)x, m); }
+    __device__ __forceinline__ void divmod(int x, int& q, int& r) const { q = div(x); r = x - q * d; }
+};
+
 // XCD-aware tile order (cdna_hip_programming.md T1): workgroups are dealt round-robin over the 8 XCDs, each with a private L2 that is cold after
 // every kernel boundary, so workgroups b, b + 8, ... share an L2.  Handing each XCD a compact (ntm / gm) x (ntn / gn) block of a task's tile grid
 // (gm gn = 8) instead of every 8th tile makes the tiles that share an A row panel or a B column panel fetch it from the Infinity Cache once per
