@@ -34,17 +34,25 @@ struct FastDiv {
     __device__ __forceinline__ void divmod(int x, int& q, int& r) const { q = div(x); r = x - q * d; }
 };
 
+// x / d for small indices through ONE v_rcp_f32 (rd = frcp(d), computed once per divisor): floor((x + 0.5) rd).  (x + 0.5) / d is at least 0.5 / d away
+// from an integer and the product is off by < (x / d) 2^-21, so the result is exact for x < 2^20 - every tile / element index here.  The integer
+// division it replaces is ~40 instructions; the 16-row kernel's prologue alone had ~30 of them per thread.
+__device__ __forceinline__ float frcp(int d) { return __builtin_amdgcn_rcpf((float)d); }
+__device__ __forceinline__ int sdiv(int x, float rd) { return (int)(((float)x + 0.5f) * rd); }
+
 // XCD-aware tile order (cdna_hip_programming.md T1): workgroups are dealt round-robin over the 8 XCDs, each with a private L2 that is cold after
 // every kernel boundary, so workgroups b, b + 8, ... share an L2.  Handing each XCD a compact (ntm / gm) x (ntn / gn) block of a task's tile grid
 // (gm gn = 8) instead of every 8th tile makes the tiles that share an A row panel or a B column panel fetch it from the Infinity Cache once per
 // XCD that needs it (gn + gm panel fetches instead of 8 + 8).  `local` = tile index inside the task, whose first workgroup is a multiple of 8.
 // Placement is a speed matter only: results do not depend on which workgroup computes which tile.
 __device__ __forceinline__ void xcd_tile(int local, int ntm, int ntn, int gm, int& tm, int& tn) {
-    const int gn = 8 / gm, x = local & 7, j = local >> 3;
-    const int bn = ntn / gn, bm = ntm / gm;
-    const int jm = j / bn;
-    tm = (x / gn) * bm + jm;
-    tn = (x - (x / gn) * gn) * bn + (j - jm * bn);
+    const int gs = 31 - __clz(gm);                      // gm is 1, 2, 4 or 8: every division below is a shift but one
+    const int x = local & 7, j = local >> 3;
+    const int bn = ntn >> (3 - gs), bm = ntm >> gs;     // ntn / gn, ntm / gm (exact: checked where the order is chosen)
+    const int xm = x >> (3 - gs);                       // x / gn
+    const int jm = sdiv(j, frcp(bn));
+    tm = xm * bm + jm;
+    tn = (x - (xm << (3 - gs))) * bn + (j - jm * bn);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -447,14 +455,14 @@ __device__ __forceinline__ void gemm_wave(f32x4 (&acc)[TMT], const BAddr& ba, co
 template <int NA, int TMT, bool EUL>
 __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
     const int local = blockIdx.x - T.tile0;
-    const int tm = local / T.ntn, tn = local - tm * T.ntn;
+    const int tm = sdiv(local, frcp(T.ntn)), tn = local - tm * T.ntn;
     const int row0 = tm * 16 * TMT;
     const int K = T.K, N = T.N;
     const int S = K + 4;  // LDS row stride (floats)
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int flags = T.flags;
-    const int WK = T.wk, NW = 4 / WK;
+    const int WK = T.wk, wks = WK >> 1, NW = 4 >> wks;   // WK is 1, 2 or 4: wks = log2(WK)
     float* red = lds + 16 * TMT * S;  // [WK-1][NW][TMT][64] float4 partial accumulators
 #ifdef FQL_STAMPS
     unsigned long long stamp[8];
@@ -468,14 +476,15 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
     // ---- issue every independent load of the tile up front: the A tile (<= 16 x 16 B per thread and row
     // tile), the wave's first two B chunks and its bias.  At one wave per SIMD only explicit parallel issue
     // hides the ~0.3-1.5 us (cold, cross-XCD) load latency; a rolled staging loop would serialise it.
-    const int nt = wave % NW, kp = wave / NW;
+    const int nt = wave & (NW - 1), kp = wave >> (2 - wks);
     const int n0 = (tn * NW + nt) * 16;
     const int c = lane & 15, q = lane >> 4;
     const bool active = n0 < N;
     const int G = K >> 4;
-    const int gbeg = (kp * G) / WK, gend = ((kp + 1) * G) / WK;
+    const int gbeg = (kp * G) >> wks, gend = ((kp + 1) * G) >> wks;
     const bool transb = (flags & GF_TRANS_B) != 0;
     const int k4 = K >> 2;
+    const float rk4 = frcp(k4);
     const int nA = 16 * k4;
     float b0[32], b1[32];
     BAddr ba = transb ? gemm_baddr<true>(T, n0, c, q) : gemm_baddr<false>(T, n0, c, q);
@@ -571,7 +580,7 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
         // critic members' input gradients (ld lda of THEIR pass = e_ntp, action block at column i1), f0 = alpha 2 / (B act).
         issue_b();
         for (int e = tid; e < 16 * K; e += FQL_THREADS) {
-            const int r = e / K, j = e - r * K;
+            const int r = sdiv(e, frcp(K)), j = e - r * K;
             float g = 0.f;
             if (j < T.i2) {
                 const float ar = ldg(T.ea_in + (size_t)(row0 + r) * T.i0 + j);
@@ -603,7 +612,7 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int f = min(tid + i * FQL_THREADS, nA - 1);  // clamped, unconditional
-            const int r = f / k4, kk = f - r * k4;
+            const int r = sdiv(f, rk4), kk = f - r * k4;
             av[i] = ldg4(Ag + (size_t)r * T.lda + 4 * kk);
         }
         if (pass == 0) issue_b();
@@ -611,7 +620,7 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
         for (int i = 0; i < NA; ++i) {
             const int f = tid + i * FQL_THREADS;
             if (f < nA) {
-                const int r = f / k4, kk = f - r * k4;
+                const int r = sdiv(f, rk4), kk = f - r * k4;
                 *reinterpret_cast<f32x4*>(&lds[(16 * pass + r) * S + 4 * kk]) = av[i];
             }
         }
@@ -866,7 +875,7 @@ __device__ __forceinline__ void gemm64_body(const GemmTask& T, float* lds) {
     float* Bs = lds + 2 * TM * G64_S;   // [2][64][G64_S]   ([k][n], or [n][k] when GF_TRANS_B)
     float* part = Bs + 2 * 64 * G64_S;  // [2][TM][2] LN partial sums of the epilogue
     const int local = (int)blockIdx.x - T.tile0;  // gemm64 tasks always come first in a launch
-    const int tm = local / T.ntn, tn = local - tm * T.ntn;
+    const int tm = sdiv(local, frcp(T.ntn)), tn = local - tm * T.ntn;
     const int row0 = tm * TM, n0 = tn * 64;
     const int K = T.K;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1071,7 +1080,7 @@ __device__ __forceinline__ void gemm32_body(const GemmTask& T, float* lds) {
     float* Bs = lds + 2 * 32 * G64_S;             // [2][BROWS][BS]
     float* part = Bs + 2 * BROWS * BS;            // [2 column halves][32][2] LN partial sums of the epilogue
     const int local = (int)blockIdx.x - T.tile0;
-    int tm = local / T.ntn, tn = local - tm * T.ntn;
+    int tm = sdiv(local, frcp(T.ntn)), tn = local - tm * T.ntn;
     if (T.xg) xcd_tile(local, T.M >> 5, T.ntn, T.xg, tm, tn);
     const int row0 = tm * 32, n0 = tn * TN;
     const int K = T.K;
@@ -1277,7 +1286,7 @@ __device__ __forceinline__ void gemm32s_body(const GemmTask& T, float* lds_f) {
     unsigned* Bs = As + 4 * APL;                          // [2 buffers][hi, lo][BPL]
     float* part = reinterpret_cast<float*>(Bs + 4 * BPL); // [2 column halves][32][2] LN partial sums of the epilogue
     const int local = (int)blockIdx.x - T.tile0;
-    int tm = local / T.ntn, tn = local - tm * T.ntn;
+    int tm = sdiv(local, frcp(T.ntn)), tn = local - tm * T.ntn;
     if (T.xg) xcd_tile(local, T.M >> 5, T.ntn, T.xg, tm, tn);
     const int row0 = tm * 32, n0 = tn * TN;
     const int K = T.K;
@@ -1542,7 +1551,7 @@ __device__ __forceinline__ void wgrad_body(const WgradTask& T, int bid, float* l
     float* red = lds;                    // [wave][tile][lane] float4
     float (*redb)[64] = reinterpret_cast<float (*)[64]>(lds + 4 * 4 * 64 * 4);
     const int local = bid - T.tile0;
-    const int tk = local / T.ntn, tn = local - tk * T.ntn;
+    const int tk = sdiv(local, frcp(T.ntn)), tn = local - tk * T.ntn;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 15, q = lane >> 4;
     const int k0 = tk * 16, n0 = tn * 64;
@@ -1604,7 +1613,7 @@ __device__ __forceinline__ void wgrad_split_body(const WgradTask& T, int bid, fl
     float* red = lds;                    // [wave][tile][lane] float4
     float (*redb)[64] = reinterpret_cast<float (*)[64]>(lds + 4 * 4 * 64 * 4);
     const int local = bid - T.tile0;
-    const int tk = local / T.ntn, tn = local - tk * T.ntn;
+    const int tk = sdiv(local, frcp(T.ntn)), tn = local - tk * T.ntn;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 15, q = lane >> 4;
     const int k0 = tk * 16, n0 = tn * 64;
@@ -1936,7 +1945,7 @@ __device__ __forceinline__ void fql_post_onestep_body(const PostOsArgs& P, float
     float se = 0.f;
     const int n = P.B * P.ad;
     for (int e = threadIdx.x; e < n; e += FQL_THREADS) {
-        const int b = e / P.ad, a = e - b * P.ad;
+        const int b = sdiv(e, frcp(P.ad)), a = e - b * P.ad;
         const float d = clip1(P.A_os[(size_t)(2 * P.B + b) * P.ap + a]) - P.w_act[(size_t)b * P.ap + a];
         se += d * d;
     }
@@ -2024,7 +2033,7 @@ __device__ __forceinline__ void fql_loss_bc_body(const LossBcArgs& P, float* sh)
     const float gs = 2.0f / (float)n;
     float s = 0.f;
     for (int e = threadIdx.x; e < n; e += FQL_THREADS) {
-        const int b = e / P.ad, a = e - b * P.ad;
+        const int b = sdiv(e, frcp(P.ad)), a = e - b * P.ad;
         const float d = P.pred[(size_t)b * P.ap + a] - P.vel[(size_t)b * P.ap + a];
         s += d * d;
         if (P.want_grad) P.dpred[(size_t)b * P.ap + a] = gs * d;
@@ -2048,7 +2057,7 @@ __device__ __forceinline__ void fql_loss_actor_body(const LossActorArgs& P, floa
     const float gs = P.alpha * 2.0f / (float)n;
     float s = 0.f;
     for (int e = threadIdx.x; e < n; e += FQL_THREADS) {
-        const int b = e / P.ad, a = e - b * P.ad;
+        const int b = sdiv(e, frcp(P.ad)), a = e - b * P.ad;
         const float ar = P.a_raw[(size_t)b * P.ap + a];
         const float d = ar - P.tgt[(size_t)b * P.ap + a];
         s += d * d;
@@ -2224,7 +2233,7 @@ struct EulerFinishArgs {
 __global__ __launch_bounds__(FQL_THREADS) void fql_euler_finish_kernel(EulerFinishArgs P) {
     const int e = blockIdx.x * FQL_THREADS + threadIdx.x;
     if (e >= P.M * P.ad) return;
-    const int r = e / P.ad, j = e - r * P.ad;
+    const int r = sdiv(e, frcp(P.ad)), j = e - r * P.ad;
     float pv[32];
 #pragma unroll
     for (int tp = 0; tp < 32; ++tp) pv[tp] = ldg(P.evp + ((size_t)min(tp, P.ntp - 1) * P.M + r) * P.ap + j);
