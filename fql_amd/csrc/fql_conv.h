@@ -776,9 +776,10 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_conv_wgrad_reduce_kernel(cons
     __syncthreads();
     if (wave != 0 || e >= total) return;
     const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-    const int k = e / P.Co, o = e - k * P.Co;
+    int k, o, t, ci;
+    FastDiv(P.Co).divmod(e, k, o);
     if (k == 9 * P.Ci) { P.db[o] = s; return; }
-    const int t = k / P.Ci, ci = k - t * P.Ci;
+    FastDiv(P.Ci).divmod(k, t, ci);
     if (ci < P.Cw_rows) P.dK[((size_t)t * P.Cw_rows + ci) * P.Co + o] = s;
 }
 
@@ -870,31 +871,44 @@ struct ImgGatherArgs {
     const unsigned char* frames2;
     const unsigned char* next_frames2;
 };
+// One thread per FOUR output bytes of obs / nobs (H W k C is a multiple of 4: checked at upload), 32-bit indices with multiply-high division
+// (the first version - one thread per byte, four 64-bit divisions each - took 53 us per update).
 __global__ __launch_bounds__(FQL_THREADS) void fql_img_gather_kernel(const ImgGatherArgs P) {
-    const int KC = P.k * P.C;
-    const size_t e = (size_t)blockIdx.x * FQL_THREADS + threadIdx.x;
-    if (e >= (size_t)P.B * P.H * P.W * KC) return;
-    const int ch = (int)(e % KC);
-    size_t r = e / KC;
-    const int x = (int)(r % P.W); r /= P.W;
-    const int y = (int)(r % P.H);
-    const int b = (int)(r / P.H);
-    const int f = ch / P.C, c = ch - f * P.C;
-    int sy = y, sx = x;
+    const int KC = P.k * P.C, rowb = P.W * KC;               // bytes per output pixel / image row
+    const unsigned e4 = blockIdx.x * FQL_THREADS + threadIdx.x;
+    const unsigned total4 = (unsigned)(((size_t)P.B * P.H * rowb) >> 2);
+    if (e4 >= total4) return;
+    const FastDiv fRow4(rowb >> 2), fH(P.H), fKC(KC), fC(P.C);
+    int r, d4, b, y;
+    fRow4.divmod((int)e4, r, d4);                             // r = image row index b H + y, d4 = dword inside the row
+    fH.divmod(r, b, y);
+    int sy = y, dx = 0;
     if (P.crop) {
         sy = min(max(y + P.crop[2 * b] - P.pad, 0), P.H - 1);
-        sx = min(max(x + P.crop[2 * b + 1] - P.pad, 0), P.W - 1);
+        dx = P.crop[2 * b + 1] - P.pad;
     }
     const int64_t t = P.idx[b], i0 = P.init[b];
-    const size_t pix = ((size_t)sy * P.W + sx) * P.C + c;
     const size_t img = (size_t)P.H * P.W * P.C;
-    // frame f of obs is ob[max(t - (k-1-f), init)]; frame f of next is the same list shifted by one with next_ob[t] last
-    const int64_t so = max(t - (P.k - 1 - f), i0);
     const bool second = P.split > 0 && b >= P.split;
     const unsigned char* fr = second ? P.frames2 : P.frames;
-    P.obs[e] = fr[(size_t)so * img + pix];
-    if (f == P.k - 1) P.nobs[e] = (second ? P.next_frames2 : P.next_frames)[(size_t)t * img + pix];
-    else P.nobs[e] = fr[(size_t)max(t - (P.k - 2 - f), i0) * img + pix];
+    const unsigned char* nf = second ? P.next_frames2 : P.next_frames;
+    unsigned wo = 0, wn = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int x, ch, f, c;
+        fKC.divmod(4 * d4 + i, x, ch);
+        fC.divmod(ch, f, c);
+        const int sx = min(max(x + dx, 0), P.W - 1);
+        const size_t pix = ((size_t)sy * P.W + sx) * P.C + c;
+        // frame f of obs is ob[max(t - (k-1-f), init)]; frame f of next is the same list shifted by one with next_ob[t] last
+        const int64_t so = max(t - (P.k - 1 - f), i0);
+        const unsigned vo = fr[(size_t)so * img + pix];
+        const unsigned vn = (f == P.k - 1) ? nf[(size_t)t * img + pix] : fr[(size_t)max(t - (P.k - 2 - f), i0) * img + pix];
+        wo |= vo << (8 * i);
+        wn |= vn << (8 * i);
+    }
+    reinterpret_cast<unsigned*>(P.obs)[e4] = wo;
+    reinterpret_cast<unsigned*>(P.nobs)[e4] = wn;
 }
 
 // index draw (utils/datasets.py:64-66), episode starts and crop offsets (utils/datasets.py:102-112) of one batch

@@ -2870,7 +2870,7 @@ struct fql_engine {
         const size_t ib = (size_t)cfg.img_h * cfg.img_w * cfg.img_c;
         ImgGatherArgs ga{ds_frames, ds_next_frames, in_idx, in_init, in_crop, img_all, img_all + (size_t)B * ib,
                          B, cfg.img_h, cfg.img_w, cfg.img_c / ds_fs, ds_fs, 3, split, rb_frames, rb_next_frames};
-        const size_t tot = (size_t)B * ib;
+        const size_t tot = ((size_t)B * ib) >> 2;   // one thread per four output bytes (img_w is a multiple of 32: rows are whole dwords)
         hipLaunchKernelGGL(fql_img_gather_kernel, dim3((unsigned)((tot + FQL_THREADS - 1) / FQL_THREADS)), dim3(FQL_THREADS), 0, s, ga);
         HIP_CHECK(hipGetLastError());
         SrcDesc d{};
