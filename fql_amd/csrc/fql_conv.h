@@ -187,9 +187,12 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
         fW.divmod(p, py, pxm);
         pbase[i] = (py * PW + pxm) * CS + 4 * q;
     }
-    float bv[CO_TILES];
+    // The product runs TRANSPOSED (weight fragment as the A operand, input fragment as B: the same registers, swapped), so lane (c, q) ends up with
+    // output channels 16 j + 4 q .. + 3 of pixel c of a tile: bias, mask, residual and both outputs are 16-byte accesses, a wave's store is 1 KB contiguous
+    // (a row block is R full image rows = R W consecutive pixels of the output tensor: no division anywhere in the epilogue).
+    f32x4 bv[CO_TILES];
 #pragma unroll
-    for (int j = 0; j < CO_TILES; ++j) bv[j] = P.bias ? ldg(P.bias + 16 * j + c) : 0.f;
+    for (int j = 0; j < CO_TILES; ++j) bv[j] = P.bias ? ldg4(P.bias + 16 * j + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
     const int ngroups = Ci >> 4;
 
     for (int blk = wg; blk < nblocks; blk += nwg) {
@@ -248,21 +251,17 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
         const int nxt = blk + nwg;
         if constexpr (PIPE) { if (nxt < nblocks) { int nn, nb; fBPI.divmod(nxt, nn, nb); T.fetch(nn, nb * R); } }
         // epilogue operands of this block: issued now, consumed after the MFMA loop
-        float mk[2][CO_TILES][4], ad[2][CO_TILES][4];
+        f32x4 mk[2][CO_TILES], ad[2][CO_TILES];
         if (PIPE)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int t = min(wave + 4 * i, ntiles - 1);
 #pragma unroll
-            for (int j = 0; j < CO_TILES; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int py, pxm;
-                    fW.divmod(16 * t + 4 * q, py, pxm);   // a lane's four pixels are consecutive in one image row (W is a multiple of 4)
-                    const size_t o = (((size_t)n * H + y0 + py) * W + pxm + r) * Co + 16 * j + c;
-                    mk[i][j][r] = P.mask ? ldg(P.mask + o) : 1.f;
-                    ad[i][j][r] = P.add ? ldg(P.add + o) : 0.f;
-                }
+            for (int j = 0; j < CO_TILES; ++j) {
+                const size_t o = ((((size_t)n * H + y0) * W) + 16 * t + c) * Co + 16 * j + 4 * q;
+                mk[i][j] = P.mask ? ldg4(P.mask + o) : f32x4{1.f, 1.f, 1.f, 1.f};
+                ad[i][j] = P.add ? ldg4(P.add + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         f32x4 acc[2][CO_TILES];
 #pragma unroll
@@ -286,48 +285,48 @@ __device__ __forceinline__ void conv_body(const ConvArgs& P, float* lds) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16_k16(al[i], bh[j], acc[i][j]);
+                        for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16_k16(bh[j], al[i], acc[i][j]);
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16_k16(ah[i], bl[j], acc[i][j]);
+                        for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16_k16(bl[j], ah[i], acc[i][j]);
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16_k16(ah[i], bh[j], acc[i][j]);
+                        for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16_k16(bh[j], ah[i], acc[i][j]);
                 } else
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < CO_TILES; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < CO_TILES; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][s], a[i][s], acc[i][j], 0, 0, 0);
             }
         }
         VSTAMP();   // [3] MFMA loop done
-        // ---- epilogue.  C layout: col = lane & 15 (channel), row = 4 q + r (pixel of the tile)
+        // ---- epilogue.  C layout of the transposed product: col = lane & 15 = pixel of the tile, row = 4 q + r = channel of the tile
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int t = wave + 4 * i;
             if (t >= ntiles) continue;
 #pragma unroll
             for (int j = 0; j < CO_TILES; ++j) {
+                const size_t o = ((((size_t)n * H + y0) * W) + 16 * t + c) * Co + 16 * j + 4 * q;
+                f32x4 v = acc[i][j] + bv[j];
+                if (PIPE) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int py, pxm;
-                    fW.divmod(16 * t + 4 * q, py, pxm);
-                    const size_t o = (((size_t)n * H + y0 + py) * W + pxm + r) * Co + 16 * j + c;
-                    float v = acc[i][j][r] + bv[j];
-                    if (PIPE) {
-                        v = (mk[i][j][r] > 0.f) ? v : 0.f;
-                        v += ad[i][j][r];
-                    } else {
-                        if (P.mask) v = (ldg(P.mask + o) > 0.f) ? v : 0.f;
-                        if (P.add) v += ldg(P.add + o);
+                    for (int r = 0; r < 4; ++r) v[r] = (mk[i][j][r] > 0.f) ? v[r] : 0.f;
+                    v += ad[i][j];
+                } else {
+                    if (P.mask) {
+                        const f32x4 m = ldg4(P.mask + o);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = (m[r] > 0.f) ? v[r] : 0.f;
                     }
-                    stg(P.out + o, v);
-                    if (P.out_relu) stg(P.out_relu + o, fmaxf(v, 0.f));
+                    if (P.add) v += ldg4(P.add + o);
                 }
+                stg4(P.out + o, v);
+                if (P.out_relu) stg4(P.out_relu + o, f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)});
             }
         }
         VSTAMP();   // [4] epilogue stored
@@ -402,9 +401,9 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& P, float* lds_f)
         fW.divmod(p, py, pxm);
         pbase[i] = (py * PW + pxm) * PSW + KW * q;
     }
-    float bv[CO_TILES];
+    f32x4 bv[CO_TILES];   // transposed product (see conv_body): a lane owns channels 16 j + 4 q .. + 3 of pixel c
 #pragma unroll
-    for (int j = 0; j < CO_TILES; ++j) bv[j] = P.bias ? ldg(P.bias + 16 * j + c) : 0.f;
+    for (int j = 0; j < CO_TILES; ++j) bv[j] = P.bias ? ldg4(P.bias + 16 * j + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
     int wbase[CO_TILES];
 #pragma unroll
     for (int j = 0; j < CO_TILES; ++j) wbase[j] = (16 * j + c) * WSW + KW * q;
@@ -479,15 +478,15 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& P, float* lds_f)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16(al[i], bh[j], acc[i][j]);
+                    for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16(bh[j], al[i], acc[i][j]);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16(ah[i], bl[j], acc[i][j]);
+                    for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16(bl[j], ah[i], acc[i][j]);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16(ah[i], bh[j], acc[i][j]);
+                    for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16(bh[j], ah[i], acc[i][j]);
             } else {
                 u32x2 ah[2], al[2], bh[CO_TILES], bl[CO_TILES];
 #pragma unroll
@@ -497,35 +496,34 @@ __device__ __forceinline__ void conv_split_body(const ConvArgs& P, float* lds_f)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16_k16(al[i], bh[j], acc[i][j]);
+                    for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16_k16(bh[j], al[i], acc[i][j]);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16_k16(ah[i], bl[j], acc[i][j]);
+                    for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16_k16(bl[j], ah[i], acc[i][j]);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16_k16(ah[i], bh[j], acc[i][j]);
+                    for (int j = 0; j < CO_TILES; ++j) acc[i][j] = mfma_bf16_k16(bh[j], ah[i], acc[i][j]);
             }
         }
-        // ---- epilogue (that of conv_body).  C layout: col = lane & 15 (channel), row = 4 q + r (pixel of the tile)
+        // ---- epilogue (that of conv_body).  Transposed product: col = lane & 15 = pixel of the tile, row = 4 q + r = channel of the tile
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int t = wave + 4 * i;
             if (t >= ntiles) continue;
 #pragma unroll
             for (int j = 0; j < CO_TILES; ++j) {
+                const size_t o = ((((size_t)n * H + y0) * W) + 16 * t + c) * Co + 16 * j + 4 * q;
+                f32x4 v = acc[i][j] + bv[j];
+                if (P.mask) {
+                    const f32x4 m = ldg4(P.mask + o);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int py, pxm;
-                    fW.divmod(16 * t + 4 * q, py, pxm);   // a lane's four pixels are consecutive in one image row
-                    const size_t o = (((size_t)n * H + y0 + py) * W + pxm + r) * Co + 16 * j + c;
-                    float v = acc[i][j][r] + bv[j];
-                    if (P.mask) v = (ldg(P.mask + o) > 0.f) ? v : 0.f;
-                    if (P.add) v += ldg(P.add + o);
-                    stg(P.out + o, v);
-                    if (P.out_relu) stg(P.out_relu + o, fmaxf(v, 0.f));
+                    for (int r = 0; r < 4; ++r) v[r] = (m[r] > 0.f) ? v[r] : 0.f;
                 }
+                if (P.add) v += ldg4(P.add + o);
+                stg4(P.out + o, v);
+                if (P.out_relu) stg4(P.out_relu + o, f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)});
             }
         }
     }  // row blocks
