@@ -1153,9 +1153,12 @@ __device__ __forceinline__ void gemm32_body(const GemmTask& T, float* lds) {
     f32x4 acc[NJ][2];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bias[NJ];
+    // The product runs TRANSPOSED (weight fragment as the A operand of the MFMA, activation fragment as B: the same registers, swapped), so lane (c, q)
+    // holds output row 16 wr + c, columns 16 (wc NJ + j) + 4 q .. + 3: bias, GELU'(z) in / out and C are 16-byte accesses, and a row's LayerNorm
+    // partial sums meet over the four q lanes (two shuffles).
+    f32x4 bias[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) bias[j] = (flags & GF_BIAS) ? ldg(T.bias + n0 + (wc * NJ + j) * 16 + c) : 0.f;
+    for (int j = 0; j < NJ; ++j) bias[j] = (flags & GF_BIAS) ? ldg4(T.bias + n0 + (wc * NJ + j) * 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](int buf) {
         const float* a = As + buf * 32 * G64_S + (16 * wr + c) * G64_S + 4 * q;
@@ -1181,7 +1184,7 @@ __device__ __forceinline__ void gemm32_body(const GemmTask& T, float* lds) {
             for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    acc[j][g & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[g & 1][s4], fb[g & 1][j][s4], acc[j][g & 1], 0, 0, 0);
+                    acc[j][g & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[g & 1][j][s4], fa[g & 1][s4], acc[j][g & 1], 0, 0, 0);
         }
     };
     // chunk ch computes from LDS slot ch & 1 while chunks ch+1 (registers) and ch+2 (in flight) follow
@@ -1204,35 +1207,41 @@ __device__ __forceinline__ void gemm32_body(const GemmTask& T, float* lds) {
     TSTAMP();   // [3] K loop done
 
     // ---- epilogue. C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
-    float s1[4], s2[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = row0 + 16 * wr + 4 * q + r;
-        s1[r] = 0.f; s2[r] = 0.f;
+    float s1 = 0.f, s2 = 0.f;   // this lane's share of its row's (sum, sum of squares) over the wave's 16 NJ columns
+    {
+        const int row = row0 + 16 * wr + c;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int n = n0 + (wc * NJ + j) * 16 + c;
+            const int n = n0 + (wc * NJ + j) * 16 + 4 * q;
             const size_t o = (size_t)row * T.ldc + n;
-            float v = acc[j][0][r] + acc[j][1][r] + bias[j];
-            if (flags & GF_SAVE_Z) { float gg, dg; gelu_both(v, gg, dg); stg(T.Zout + o, dg); v = (flags & GF_GELU) ? gg : v; }
-            else if (flags & GF_GELU) v = gelu_f(v);
-            if (flags & GF_GELUGRAD) v *= ldg(T.Zprev + o);
-            if (flags & GF_RELUGRAD) v = (ldg(T.Zprev + o) > 0.f) ? v : 0.f;
-            stg(T.C + o, v);
-            s1[r] += v; s2[r] += v * v;
+            f32x4 v = acc[j][0] + acc[j][1] + bias[j];
+            if (flags & GF_SAVE_Z) {
+                f32x4 dgv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { float gg, dg; gelu_both(v[r], gg, dg); dgv[r] = dg; v[r] = (flags & GF_GELU) ? gg : v[r]; }
+                stg4(T.Zout + o, dgv);
+            } else if (flags & GF_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+            }
+            if (flags & GF_GELUGRAD) v *= ldg4(T.Zprev + o);
+            if (flags & GF_RELUGRAD) {
+                const f32x4 zp = ldg4(T.Zprev + o);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (zp[r] > 0.f) ? v[r] : 0.f;
+            }
+            stg4(T.C + o, v);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s1 += v[r]; s2 += v[r] * v[r]; }
         }
     }
     if (flags & GF_LN_PART) {   // per-row (sum, sum of squares) of each 32-column half: T.i1 = N / 32 partials per row
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float a = s1[r], b = s2[r];
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-            if (c == 0) {
-                const int rl = 16 * wr + 4 * q + r;
-                part[(wc * 32 + rl) * 2] = a;
-                part[(wc * 32 + rl) * 2 + 1] = b;
-            }
+        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        if (q == 0) {
+            const int rl = 16 * wr + c;
+            part[(wc * 32 + rl) * 2] = s1;
+            part[(wc * 32 + rl) * 2 + 1] = s2;
         }
         __syncthreads();
         const int rs = (2 * T.i1 + 3) & ~3;
@@ -1380,9 +1389,12 @@ __device__ __forceinline__ void gemm32s_body(const GemmTask& T, float* lds_f) {
     f32x4 acc[NJ][2];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bias[NJ];
+    // The product runs TRANSPOSED (weight fragment as the A operand of the MFMA, activation fragment as B: the same registers, swapped), so lane (c, q)
+    // holds output row 16 wr + c, columns 16 (wc NJ + j) + 4 q .. + 3: bias, GELU'(z) in / out and C are 16-byte accesses, and a row's LayerNorm
+    // partial sums meet over the four q lanes (two shuffles).
+    f32x4 bias[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) bias[j] = (flags & GF_BIAS) ? ldg(T.bias + n0 + (wc * NJ + j) * 16 + c) : 0.f;
+    for (int j = 0; j < NJ; ++j) bias[j] = (flags & GF_BIAS) ? ldg4(T.bias + n0 + (wc * NJ + j) * 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
 
     // fragment addresses (words) that do not depend on the chunk
     const int a_row = (16 * wr + c) * 32, sw = (c >> 1) & 7;
@@ -1414,11 +1426,11 @@ __device__ __forceinline__ void gemm32s_body(const GemmTask& T, float* lds_f) {
                 }
             }
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[j][0] = mfma_bf16(fah, fbh[j], acc[j][0]);
+            for (int j = 0; j < NJ; ++j) acc[j][0] = mfma_bf16(fbh[j], fah, acc[j][0]);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[j][1] = mfma_bf16(fah, fbl[j], acc[j][1]);
+            for (int j = 0; j < NJ; ++j) acc[j][1] = mfma_bf16(fbl[j], fah, acc[j][1]);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[j][1] = mfma_bf16(fal, fbh[j], acc[j][1]);
+            for (int j = 0; j < NJ; ++j) acc[j][1] = mfma_bf16(fbh[j], fal, acc[j][1]);
         }
     };
     // chunk ch computes from LDS slot ch & 1 while chunks ch+1 (registers) and ch+2 (in flight) follow
@@ -1441,35 +1453,41 @@ __device__ __forceinline__ void gemm32s_body(const GemmTask& T, float* lds_f) {
 
     SSTAMP();   // [3] K loop done
     // ---- epilogue (that of gemm32_body). C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
-    float s1[4], s2[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = row0 + 16 * wr + 4 * q + r;
-        s1[r] = 0.f; s2[r] = 0.f;
+    float s1 = 0.f, s2 = 0.f;   // this lane's share of its row's (sum, sum of squares) over the wave's 16 NJ columns
+    {
+        const int row = row0 + 16 * wr + c;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int n = n0 + (wc * NJ + j) * 16 + c;
+            const int n = n0 + (wc * NJ + j) * 16 + 4 * q;
             const size_t o = (size_t)row * T.ldc + n;
-            float v = acc[j][0][r] + acc[j][1][r] + bias[j];
-            if (flags & GF_SAVE_Z) { float gg, dg; gelu_both(v, gg, dg); stg(T.Zout + o, dg); v = (flags & GF_GELU) ? gg : v; }
-            else if (flags & GF_GELU) v = gelu_f(v);
-            if (flags & GF_GELUGRAD) v *= ldg(T.Zprev + o);
-            if (flags & GF_RELUGRAD) v = (ldg(T.Zprev + o) > 0.f) ? v : 0.f;
-            stg(T.C + o, v);
-            s1[r] += v; s2[r] += v * v;
+            f32x4 v = acc[j][0] + acc[j][1] + bias[j];
+            if (flags & GF_SAVE_Z) {
+                f32x4 dgv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { float gg, dg; gelu_both(v[r], gg, dg); dgv[r] = dg; v[r] = (flags & GF_GELU) ? gg : v[r]; }
+                stg4(T.Zout + o, dgv);
+            } else if (flags & GF_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+            }
+            if (flags & GF_GELUGRAD) v *= ldg4(T.Zprev + o);
+            if (flags & GF_RELUGRAD) {
+                const f32x4 zp = ldg4(T.Zprev + o);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (zp[r] > 0.f) ? v[r] : 0.f;
+            }
+            stg4(T.C + o, v);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s1 += v[r]; s2 += v[r] * v[r]; }
         }
     }
     if (flags & GF_LN_PART) {   // per-row (sum, sum of squares) of each 32-column half: T.i1 = N / 32 partials per row
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float a = s1[r], b = s2[r];
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-            if (c == 0) {
-                const int rl = 16 * wr + 4 * q + r;
-                part[(wc * 32 + rl) * 2] = a;
-                part[(wc * 32 + rl) * 2 + 1] = b;
-            }
+        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        if (q == 0) {
+            const int rl = 16 * wr + c;
+            part[(wc * 32 + rl) * 2] = s1;
+            part[(wc * 32 + rl) * 2 + 1] = s2;
         }
         __syncthreads();
         const int rs = (2 * T.i1 + 3) & ~3;

@@ -225,8 +225,8 @@ def test_visual_full_size_is_deterministic_and_consistent(precision):
     assert ia == ib
     assert all(np.isfinite(v) for v in ia.values())
     for k in ('critic/critic_loss', 'actor/actor_loss', 'actor/bc_flow_loss', 'actor/distill_loss', 'actor/q_loss', 'actor/mse'):
-        if precision == 'fp32':
-            assert itl[k] == ib[k], k                                        # same kernels, same inputs: bitwise
+        if precision == 'fp32':   # same kernels, same inputs; the forward-only program may pick another tile shape for a launch, and a row's LayerNorm
+            assert abs(itl[k] - ib[k]) <= 1e-6 * max(1.0, abs(ib[k])), (k, itl[k], ib[k])   # statistics are then summed in another order: rounding, not bitwise
         else:   # the forward-only program may leave a product on the 16-row fp32 kernel that the update program runs on a split tile
             assert abs(itl[k] - ib[k]) <= 2e-4 * max(1.0, abs(ib[k])), (k, itl[k], ib[k])
     assert abs(loss - (ib['critic/critic_loss'] + ib['actor/actor_loss'])) <= 1e-5 * abs(loss)
