@@ -1589,7 +1589,7 @@ __device__ __forceinline__ void wgrad_body(const WgradTask& T, int bid, float* l
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 bs[t] += b[4 * i + t];
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[4 * i + t], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[4 * i + t], a[i], acc[t], 0, 0, 0);   // transposed: a lane owns dW[k0 + c][n0 + 16 t + 4 q .. + 3]
             }
     };
     wgrad_load_chunk(a0, b0, xp, zp, sx, sz, steps, ntv);
@@ -1614,8 +1614,7 @@ __device__ __forceinline__ void wgrad_body(const WgradTask& T, int bid, float* l
         f32x4 r = *reinterpret_cast<const f32x4*>(&red[((0 * 4 + wave) * 64 + lane) * 4]);
 #pragma unroll
         for (int w = 1; w < 4; ++w) r += *reinterpret_cast<const f32x4*>(&red[((w * 4 + wave) * 64 + lane) * 4]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) stg(T.dW + (size_t)(k0 + 4 * q + i) * T.ldw + n0 + 16 * wave + c, r[i]);
+        stg4(T.dW + (size_t)(k0 + c) * T.ldw + n0 + 16 * wave + 4 * q, r);   // one 16-byte store per lane (the product is transposed)
         if (tk == 0 && T.db && q == 0) {
             const int j = 16 * wave + c;
             T.db[n0 + j] = redb[0][j] + redb[1][j] + redb[2][j] + redb[3][j];
@@ -1676,9 +1675,9 @@ __device__ __forceinline__ void wgrad_split_body(const WgradTask& T, int bid, fl
                 bsplit2(b0v, b1v, h, l);
                 bh[i] = h; bl[i] = l;
             }
-            acc[t] = mfma_bf16(al, bh, acc[t]);
-            acc[t] = mfma_bf16(ah, bl, acc[t]);
-            acc[t] = mfma_bf16(ah, bh, acc[t]);
+            acc[t] = mfma_bf16(bh, al, acc[t]);   // transposed product (see wgrad_body): dW[k0 + c][n0 + 16 t + 4 q .. + 3]
+            acc[t] = mfma_bf16(bl, ah, acc[t]);
+            acc[t] = mfma_bf16(bh, ah, acc[t]);
             __builtin_amdgcn_sched_barrier(0);   // keeps the compiler from hoisting every split in front of the MFMAs (spills)
         }
     };
@@ -1704,8 +1703,7 @@ __device__ __forceinline__ void wgrad_split_body(const WgradTask& T, int bid, fl
         f32x4 r = *reinterpret_cast<const f32x4*>(&red[((0 * 4 + wave) * 64 + lane) * 4]);
 #pragma unroll
         for (int w = 1; w < 4; ++w) r += *reinterpret_cast<const f32x4*>(&red[((w * 4 + wave) * 64 + lane) * 4]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) stg(T.dW + (size_t)(k0 + 4 * q + i) * T.ldw + n0 + 16 * wave + c, r[i]);
+        stg4(T.dW + (size_t)(k0 + c) * T.ldw + n0 + 16 * wave + 4 * q, r);   // one 16-byte store per lane (the product is transposed)
         if (tk == 0 && T.db && q == 0) {
             const int j = 16 * wave + c;
             T.db[n0 + j] = redb[0][j] + redb[1][j] + redb[2][j] + redb[3][j];
