@@ -1734,25 +1734,33 @@ __device__ __forceinline__ void lnbwd_body(const LnBwdTask& T, int bid, float (*
         const float* z = T.Z + (size_t)row * T.ld;
         const float* gv = T.Gv + (size_t)row * T.ld;
         const float dqr = SYN ? ldg(T.dq + (size_t)row * T.ldq) : 0.f;
-        float zz[16], dd[16], gm[16], gq[16];  // H <= 1024: <= 16 elements per lane, k = lane + 64 i; all loads issued first
+        // H <= 1024 (a multiple of 16): <= 4 float4 per lane and tensor, columns 4 (lane + 64 i) ..; every load is issued first.  (Round 1 read 16
+        // single floats per lane and tensor whatever H was - at H = 512 half of those 64 loads were clamped duplicates.)
+        f32x4 zz[4], dd[4], gm[4], gq[4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int k = min(lane + 64 * i, T.H - 1);
-            zz[i] = ldg(z + k);
-            gq[i] = ldg(gv + k);
-            dd[i] = SYN ? dqr * ldg(T.wq + (size_t)k * T.ldw) : ldg(dy + k);
-            gm[i] = ldg(T.gamma + k);
+        for (int i = 0; i < 4; ++i) {
+            const int k4 = 4 * (lane + 64 * i);
+            if (k4 < T.H) {
+                zz[i] = ldg4(z + k4);
+                gq[i] = ldg4(gv + k4);
+                gm[i] = ldg4(T.gamma + k4);
+                if (SYN) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dd[i][e] = dqr * ldg(T.wq + (size_t)(k4 + e) * T.ldw);
+                } else dd[i] = ldg4(dy + k4);
+            } else zz[i] = gq[i] = gm[i] = dd[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        float d[16], xh[16], dg[16];
+        f32x4 d[4], xh[4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int k = lane + 64 * i;
-            dg[i] = zz[i];
-            xh[i] = (gq[i] - mean) * rstd;
-            d[i] = dd[i] * gm[i];
-            if (k < T.width) { s1 += d[i]; s2 += d[i] * xh[i]; }
-        }
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 4 * (lane + 64 * i) + e;
+                xh[i][e] = (gq[i][e] - mean) * rstd;
+                d[i][e] = dd[i][e] * gm[i][e];
+                if (k < T.width) { s1 += d[i][e]; s2 += d[i][e] * xh[i][e]; }
+            }
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             s1 += __shfl_xor(s1, o);
@@ -1762,9 +1770,14 @@ __device__ __forceinline__ void lnbwd_body(const LnBwdTask& T, int bid, float (*
         const float m1 = s1 * inv, m2 = s2 * inv;
         float* dz = T.dZ + (size_t)row * T.ld;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int k = lane + 64 * i;
-            if (k < T.H) stg(dz + k, (k < T.width) ? rstd * (d[i] - m1 - xh[i] * m2) * dg[i] : 0.f);
+        for (int i = 0; i < 4; ++i) {
+            const int k4 = 4 * (lane + 64 * i);
+            if (k4 < T.H) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (k4 + e < T.width) ? rstd * (d[i][e] - m1 - xh[i][e] * m2) * zz[i][e] : 0.f;
+                stg4(dz + k4, o);
+            }
         }
     } else {
         const int cc = threadIdx.x & 15, rg = threadIdx.x >> 4;
