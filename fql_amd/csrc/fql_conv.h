@@ -795,7 +795,8 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_maxpool_kernel(const PoolArgs
     const int c4 = P.C >> 2, Ho = P.H >> 1, Wo = P.W >> 1;
     const size_t e64 = (size_t)blockIdx.x * FQL_THREADS + threadIdx.x;
     if (e64 >= (size_t)P.N * Ho * Wo * c4) return;   // (< 2^31 elements: checked where the op is emitted)
-    const FastDiv fC4(c4), fWo(Wo), fHo(Ho);
+    if (e64 >> 31) return;   // (flat indices stay below 2^31: checked where the op is emitted)
+    const FastDiv fC4(c4, e64), fWo(Wo, e64), fHo(Ho, e64);
     int cc, r, ox, oy, n;
     fC4.divmod((int)e64, r, cc);
     fWo.divmod(r, r, ox);
@@ -828,7 +829,8 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_maxpool_bwd_kernel(const Pool
     const int c4 = P.C >> 2, Ho = P.H >> 1, Wo = P.W >> 1;
     const size_t e64 = (size_t)blockIdx.x * FQL_THREADS + threadIdx.x;
     if (e64 >= (size_t)P.N * P.H * P.W * c4) return;   // (< 2^31 elements)
-    const FastDiv fC4(c4), fW(P.W), fH(P.H);
+    if (e64 >> 31) return;
+    const FastDiv fC4(c4, e64), fW(P.W, e64), fH(P.H, e64);
     int cc, r, x, y, n;
     fC4.divmod((int)e64, r, cc);
     fW.divmod(r, r, x);
@@ -876,7 +878,8 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_img_gather_kernel(const ImgGa
     const unsigned e4 = blockIdx.x * FQL_THREADS + threadIdx.x;
     const unsigned total4 = (unsigned)(((size_t)P.B * P.H * rowb) >> 2);
     if (e4 >= total4) return;
-    const FastDiv fRow4(rowb >> 2), fH(P.H), fKC(KC), fC(P.C);
+    if (e4 >> 31) return;   // (B H W k C < 2^33 bytes)
+    const FastDiv fRow4(rowb >> 2, e4), fH(P.H, e4), fKC(KC), fC(P.C);
     int r, d4, b, y;
     fRow4.divmod((int)e4, r, d4);                             // r = image row index b H + y, d4 = dword inside the row
     fH.divmod(r, b, y);

@@ -27,10 +27,12 @@ __device__ __forceinline__ void stg4(float* p, f32x4 v) { *(FQL_GAS f32x4*)p = v
 // q = umulhi(x, ceil(2^32 / d)), exact whenever x d < 2^32.  The convolution / pooling kernels index pixels through W, W + 2, channel quads ...: their
 // epilogues and staging loops were bound by these divisions (experiments/conv_bench_st: 4.1 us of staging per 7.8 us workgroup against 1.65 us of MFMA).
 struct FastDiv {
-    unsigned m;
+    unsigned m;   // 0: plain division (d == 1, or the caller's largest dividend is out of the exact range)
     int d;
     __device__ __forceinline__ explicit FastDiv(int dd) : m(dd > 1 ? 0xFFFFFFFFu / (unsigned)dd + 1u : 0u), d(dd) {}
-    __device__ __forceinline__ int div(int x) const { return d == 1 ? x : (int)__umulhi((unsigned)x, m); }
+    // for dividends that grow with the batch (flat element indices): falls back to the plain division when max_x d >= 2^32
+    __device__ __forceinline__ FastDiv(int dd, unsigned long long max_x) : m(dd > 1 && max_x * (unsigned long long)dd < (1ull << 32) ? 0xFFFFFFFFu / (unsigned)dd + 1u : 0u), d(dd) {}
+    __device__ __forceinline__ int div(int x) const { return m ? (int)__umulhi((unsigned)x, m) : (d == 1 ? x : (int)((unsigned)x / (unsigned)d)); }
     __device__ __forceinline__ void divmod(int x, int& q, int& r) const { q = div(x); r = x - q * d; }
 };
 
