@@ -39,6 +39,8 @@ struct ConvArgs {
     int transposed;       // 0 forward, 1 data gradient (informational: Wl is the matching layout)
     int R;                // image rows per workgroup
     int tile0, nwg;       // first workgroup of this task inside a shared launch, and how many it has
+    unsigned char* parg;  // uint8 first convolution fused with the stack's max-pool (fql_conv3x3_u8_pool_kernel): `out` is then the POOLED tensor
+                          // [N, H/2, W/2, Co] and parg its argmax codes; the pre-pool tensor is never written
 #ifdef FQL_STAMPS
     unsigned long long* stamps;   // diagnostics build (experiments/conv_bench.hip): [workgroup][8] wall-clock stamps of the first row block
 #endif
@@ -355,6 +357,145 @@ __global__ __launch_bounds__(FQL_THREADS, 3) void fql_conv3x3_u8_kernel(const Co
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const ConvArgs& P = tasks[find_task(tasks, ntasks, blockIdx.x)];
     conv_body<1, true>(P, lds);   // the first convolution of every supported encoder has 16 output channels (checked where the op is emitted)
+}
+
+// ------------------------------------------------------------------------------------------------
+// uint8 first convolution + max_pool 3x3 / stride 2 / SAME of the same stack in ONE kernel (utils/encoders.py:19-33).  The pre-pool tensor
+// (N H W 16 floats: 335 MB at B = 256 for the five encoder passes) was written once and read once by the pool kernel; here a workgroup
+// computes the FIVE convolution rows 4 pr .. 4 pr + 4 two pooled rows need (one row of overlap between neighbouring workgroups: 25 % more
+// convolution work, on a layer that is bound by its output write), parks them in LDS - the transposed product leaves a lane with four
+// channels of a pixel, one 16-byte LDS store - and pools from there: window rows 2 oy .. 2 oy + 2, the -inf padding at the end, first maximum
+// in window order (fql_maxpool_kernel's rule, bit for bit).  One workgroup per (image, pooled row pair); uint8 rows unpacked on the LDS store.
+// SPLITR: precision = 2 (fragments split in registers, v_mfma_f32_16x16x16_bf16).
+// ------------------------------------------------------------------------------------------------
+template <bool SPLITR, int NT>   // NT: pixel tiles per wave, 5 W / 64 rounded up (5 for W <= 64, 10 for W <= 128)
+__device__ __forceinline__ void conv_u8_pool_body(const ConvArgs& P, float* lds) {
+    constexpr int Ci = 16, Co = 16, CS = Ci + 4, WS = 9 * Ci + 4, OS = Co + 4;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 15, q = lane >> 4;
+    const int H = P.H, W = P.W, PW = W + 2, Cr = P.Ci_real;
+    const int prs = (H + 3) >> 2;                        // pooled row pairs per image
+    float* in_s = lds;                                   // [7][PW][CS]; reused as the convolution tile c_s [5][W][OS] once the MFMAs are done
+    const int in_fl = 7 * PW * CS, cs_fl = 5 * W * OS;
+    float* w_s = lds + (in_fl > cs_fl ? in_fl : cs_fl);  // [Co][WS]
+    const int wg = (int)blockIdx.x - P.tile0;
+    const FastDiv fPR(prs);
+    int n, pr;
+    fPR.divmod(wg, n, pr);
+    const int y0 = 4 * pr;                               // first convolution row of this workgroup
+    // ---- weights and input rows (y0 - 1 .. y0 + 5) -> LDS
+    {
+        const int total = (Co * WS) >> 2;
+        for (int e = tid; e < total; e += FQL_THREADS) *reinterpret_cast<f32x4*>(w_s + 4 * e) = ldg4(P.Wl + 4 * e);
+        for (int e = tid; e < in_fl; e += FQL_THREADS) in_s[e] = 0.f;   // halo columns, channel padding, rows outside the image
+    }
+    __syncthreads();
+    {
+        const int dpr = (W * Cr) >> 2, total = 7 * dpr;  // dwords per image row
+        const FastDiv fdpr(dpr), fCr(Cr);
+        const unsigned* src = (const unsigned*)((const unsigned char*)P.in + (size_t)n * H * W * Cr);
+        unsigned pw[4];
+        int rr[4], cd[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = min(tid + i * FQL_THREADS, total - 1);
+            fdpr.divmod(e, rr[i], cd[i]);
+            const int yy = min(max(y0 + rr[i] - 1, 0), H - 1);
+            pw[i] = __builtin_nontemporal_load(src + (size_t)yy * dpr + cd[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + i * FQL_THREADS;
+            const int yy = y0 + rr[i] - 1;
+            if (e >= total || yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int x, ch;
+                fCr.divmod(4 * cd[i] + k, x, ch);
+                in_s[(rr[i] * PW + x + 1) * CS + ch] = (float)((pw[i] >> (8 * k)) & 255u) * (1.0f / 255.0f);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 5 rows x W pixels = 5 W / 16 pixel tiles, dealt to the four waves; a tile never crosses a row (W is a multiple of 16)
+    const int ntiles = 5 * W / 16;
+    f32x4 acc[NT];
+    int pbase[NT];
+    const FastDiv fW(W);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int t = min(wave + 4 * i, ntiles - 1);
+        int py, px;
+        fW.divmod(16 * t + c, py, px);
+        pbase[i] = (py * PW + px) * CS + 4 * q;
+    }
+    const int nmine = (ntiles - wave + 3) >> 2;          // tiles of this wave
+    const f32x4 bv = P.bias ? ldg4(P.bias + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 9; ++t) {
+        const int toff = ((t / 3) * PW + (t % 3)) * CS;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(w_s + c * WS + t * Ci + 4 * q);
+        u32x2 bh, bl;
+        if constexpr (SPLITR) bsplit4(b, bh, bl);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {   // (clamped duplicate tiles of the last wave are computed and dropped: every accumulator index stays static)
+            const f32x4 a = *reinterpret_cast<const f32x4*>(in_s + pbase[i] + toff);
+            if constexpr (SPLITR) {
+                u32x2 ah, al;
+                bsplit4(a, ah, al);
+                acc[i] = mfma_bf16_k16(bh, al, acc[i]);
+                acc[i] = mfma_bf16_k16(bl, ah, acc[i]);
+                acc[i] = mfma_bf16_k16(bh, ah, acc[i]);
+            } else {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s4], a[s4], acc[i], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();   // every fragment read of in_s is done: the region becomes the convolution tile
+    float* c_s = in_s;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int t = wave + 4 * i;
+        if (i < nmine) *reinterpret_cast<f32x4*>(c_s + (16 * t + c) * OS + 4 * q) = acc[i] + bv;   // pixel 16 t + c of the 5 x W tile, channels 4 q .. 4 q + 3
+    }
+    __syncthreads();
+    // ---- pool: 2 rows x W / 2 windows x 4 channel quads, one float4 per thread and round
+    const int Wo = W >> 1, Ho = H >> 1;
+    const int nout = 2 * Wo * 4;
+    for (int e = tid; e < nout; e += FQL_THREADS) {
+        const int cq = e & 3, r2 = e >> 2;
+        const int orow = r2 >= Wo ? 1 : 0, ox = r2 - orow * Wo;
+        const int oy = 2 * pr + orow;
+        if (oy >= Ho) continue;
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int arg[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int ly = 2 * orow + i, x = 2 * ox + j;      // local convolution row, column
+                if (y0 + ly >= H || x >= W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(c_s + (ly * W + x) * OS + 4 * cq);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (v[k] > best[k]) { best[k] = v[k]; arg[k] = 3 * i + j; }
+            }
+        const size_t o = (((size_t)n * Ho + oy) * Wo + ox) * Co + 4 * cq;
+        stg4(P.out + o, best);
+        *reinterpret_cast<uchar4*>(P.parg + o) = make_uchar4((unsigned char)arg[0], (unsigned char)arg[1], (unsigned char)arg[2], (unsigned char)arg[3]);
+    }
+}
+#define FQL_CONV_U8_POOL_LDS_FLOATS(W) ((7 * ((W) + 2) * 20 > 5 * (W) * 20 ? 7 * ((W) + 2) * 20 : 5 * (W) * 20) + 16 * (9 * 16 + 4))
+__global__ __launch_bounds__(FQL_THREADS, 3) void fql_conv3x3_u8_pool_kernel(const ConvArgs* __restrict__ tasks, int ntasks) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const ConvArgs& P = tasks[find_task(tasks, ntasks, blockIdx.x)];
+    if (P.W <= 64) conv_u8_pool_body<false, 5>(P, lds); else conv_u8_pool_body<false, 10>(P, lds);
+}
+__global__ __launch_bounds__(FQL_THREADS, 3) void fql_conv3x3_u8_pool_split_kernel(const ConvArgs* __restrict__ tasks, int ntasks) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const ConvArgs& P = tasks[find_task(tasks, ntasks, blockIdx.x)];
+    if (P.W <= 64) conv_u8_pool_body<true, 5>(P, lds); else conv_u8_pool_body<true, 10>(P, lds);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -161,6 +161,7 @@ struct Launch {
     size_t lds = 0;
     void* table = nullptr;  // device task table (GEMM/WGRAD/LNBWD)
     Op op;                  // arg-struct kernels
+    bool pool_fused = false; // OP_CONV_U8: the stack's max-pool runs inside the convolution kernel (fql_conv3x3_u8_pool_kernel)
     ChainArgs chain2{};     // OP_CHAIN variant E: second task of the launch (the other ensemble member)
     bool chain_pair = false;
     int lane = 0;
@@ -765,8 +766,17 @@ struct fql_engine {
             const EncStack& st = en.stacks[s];
             EncBuf::St& bs = b.st[s];
             const int C = st.conv[0].cout, H2 = st.H / 2, W2 = st.W / 2;
+            // the uint8 first convolution and the stack's max-pool as one kernel: the pre-pool tensor (the largest write of the update) is never materialised
+            static const bool fuse_pool_env = getenv("FQL_NO_FUSE_POOL") == nullptr;
+            const bool fuse_pool = fuse_pool_env && s == 0 && C == 16 && st.W % 16 == 0 && st.W <= 128 && st.H % 2 == 0 && pad16c(st.conv[0].cin) == 16 &&
+                                   7 * st.W * st.conv[0].cin <= 4 * 4 * FQL_THREADS && (st.W * st.conv[0].cin) % 4 == 0;   // (seven input rows: <= 4 dwords per thread)
             if (s == 0) emit_conv(pr, b.img, b.img, 2, n, st.H, st.W, st.conv[0], false, bs.c0, bs.c0, nullptr, nullptr, nullptr, nullptr, nullptr);
             else emit_conv(pr, x, x, 0, n, st.H, st.W, st.conv[0], false, bs.c0, bs.c0, nullptr, nullptr, nullptr, nullptr, nullptr);
+            if (fuse_pool) {
+                Op& co = pr.ops.back();
+                co.conv.out = bs.pool; co.conv.parg = bs.arg;
+                co.writes = {bs.pool, bs.arg};
+            } else
             {
                 Op op{};
                 op.type = OP_POOL;
@@ -1556,6 +1566,11 @@ struct fql_engine {
                             static const int conv_per_cu = getenv("FQL_CONV_WGS_PER_CU") ? atoi(getenv("FQL_CONV_WGS_PER_CU")) : 0;
                             const int per_cu = ty == OP_CONV_U8 ? u8_per_cu : conv_per_cu;
                             a.nwg = per_cu > 0 ? std::min(nb, std::max(1, (int)(((long long)per_cu * num_cus * nb) / nb_all))) : nb;
+                            if (a.parg) {   // convolution + max-pool in one kernel: a workgroup per (image, pooled row pair)
+                                a.nwg = a.N * ((a.H + 3) / 4);
+                                L.pool_fused = true;
+                                L.lds = std::max(L.lds, (size_t)FQL_CONV_U8_POOL_LDS_FLOATS(a.W) * sizeof(float));
+                            }
                             tile += a.nwg;
                             L.lds = std::max(L.lds, ((size_t)(a.R + 2) * (a.W + 2) * (a.Ci + 4) + (size_t)a.Co * (9 * a.Ci + 4)) * sizeof(float));
                             if (ty == OP_CONV && cfg.precision == 2) L.lds = std::max(L.lds, (size_t)FQL_CONV_SPLIT_LDS_WORDS(a.R, a.W, a.Ci, a.Co) * sizeof(float));
@@ -1835,7 +1850,9 @@ struct fql_engine {
                 FQL_LAUNCH(fql_conv3x3_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
                 break;
             case OP_CONV_U8:
-                if (cfg.precision == 2 && u8_split) FQL_LAUNCH(fql_conv3x3_u8_split_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
+                if (L.pool_fused && cfg.precision == 2) FQL_LAUNCH(fql_conv3x3_u8_pool_split_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
+                else if (L.pool_fused) FQL_LAUNCH(fql_conv3x3_u8_pool_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
+                else if (cfg.precision == 2 && u8_split) FQL_LAUNCH(fql_conv3x3_u8_split_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
                 else
                 FQL_LAUNCH(fql_conv3x3_u8_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
                 break;
