@@ -39,7 +39,7 @@ struct ConvArgs {
     int transposed;       // 0 forward, 1 data gradient (informational: Wl is the matching layout)
     int R;                // image rows per workgroup
     int tile0, nwg;       // first workgroup of this task inside a shared launch, and how many it has
-    unsigned char* parg;  // uint8 first convolution fused with the stack's max-pool (fql_conv3x3_u8_pool_kernel): `out` is then the POOLED tensor
+    unsigned char* parg;  // uint8 first convolution fused with the stack's max-pool (fql_conv3x3_pool_kernel): `out` is then the POOLED tensor
                           // [N, H/2, W/2, Co] and parg its argmax codes; the pre-pool tensor is never written
 #ifdef FQL_STAMPS
     unsigned long long* stamps;   // diagnostics build (experiments/conv_bench.hip): [workgroup][8] wall-clock stamps of the first row block
@@ -368,12 +368,14 @@ __global__ __launch_bounds__(FQL_THREADS, 3) void fql_conv3x3_u8_kernel(const Co
 // in window order (fql_maxpool_kernel's rule, bit for bit).  One workgroup per (image, pooled row pair); uint8 rows unpacked on the LDS store.
 // SPLITR: precision = 2 (fragments split in registers, v_mfma_f32_16x16x16_bf16).
 // ------------------------------------------------------------------------------------------------
-template <bool SPLITR, int NT>   // NT: pixel tiles per wave, 5 W / 64 rounded up (5 for W <= 64, 10 for W <= 128)
-__device__ __forceinline__ void conv_u8_pool_body(const ConvArgs& P, float* lds) {
-    constexpr int Ci = 16, Co = 16, CS = Ci + 4, WS = 9 * Ci + 4, OS = Co + 4;
+// U8: uint8 input (first layer, 16 padded input channels, 16 output channels); else float NHWC input with CI channels (the first convolution of stacks 1, 2).
+// NT: pixel tiles per wave = 5 W / 64 rounded up.
+template <bool U8, int CI, int CO_TILES, bool SPLITR, int NT>
+__device__ __forceinline__ void conv_pool_body(const ConvArgs& P, float* lds) {
+    constexpr int Co = 16 * CO_TILES, CS = CI + 4, WS = 9 * CI + 4, OS = Co + 4;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 15, q = lane >> 4;
-    const int H = P.H, W = P.W, PW = W + 2, Cr = P.Ci_real;
+    const int H = P.H, W = P.W, PW = W + 2;
     const int prs = (H + 3) >> 2;                        // pooled row pairs per image
     float* in_s = lds;                                   // [7][PW][CS]; reused as the convolution tile c_s [5][W][OS] once the MFMAs are done
     const int in_fl = 7 * PW * CS, cs_fl = 5 * W * OS;
@@ -387,10 +389,11 @@ __device__ __forceinline__ void conv_u8_pool_body(const ConvArgs& P, float* lds)
     {
         const int total = (Co * WS) >> 2;
         for (int e = tid; e < total; e += FQL_THREADS) *reinterpret_cast<f32x4*>(w_s + 4 * e) = ldg4(P.Wl + 4 * e);
-        for (int e = tid; e < in_fl; e += FQL_THREADS) in_s[e] = 0.f;   // halo columns, channel padding, rows outside the image
+        if (U8) for (int e = tid; e < in_fl; e += FQL_THREADS) in_s[e] = 0.f;   // halo columns, channel padding, rows outside the image
     }
-    __syncthreads();
-    {
+    if (U8) __syncthreads();
+    if constexpr (U8) {
+        const int Cr = P.Ci_real;
         const int dpr = (W * Cr) >> 2, total = 7 * dpr;  // dwords per image row
         const FastDiv fdpr(dpr), fCr(Cr);
         const unsigned* src = (const unsigned*)((const unsigned char*)P.in + (size_t)n * H * W * Cr);
@@ -415,40 +418,82 @@ __device__ __forceinline__ void conv_u8_pool_body(const ConvArgs& P, float* lds)
                 in_s[(rr[i] * PW + x + 1) * CS + ch] = (float)((pw[i] >> (8 * k)) & 255u) * (1.0f / 255.0f);
             }
         }
+    } else {   // float rows: 7 PW CI / 4 float4 (<= 4 per thread for the supported layers, requested together), zero halo / outside rows
+        const float* src = (const float*)P.in + (size_t)n * H * W * CI;
+        constexpr int c4 = CI >> 2;
+        const int total = 7 * PW * c4;
+        const FastDiv fPW(PW);
+        f32x4 sv[4];
+        int so[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + i * FQL_THREADS, ec = min(e, total - 1);
+            const int cc = ec % c4, px = ec / c4;
+            int prow, xx;
+            fPW.divmod(px, prow, xx);
+            xx -= 1;
+            const int yy = y0 + prow - 1;
+            const bool inb = e < total && xx >= 0 && xx < W && yy >= 0 && yy < H;
+            sv[i] = ldg4(src + ((size_t)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)) * CI + 4 * cc);
+            so[i] = e < total ? ((px * CS + 4 * cc) << 1) | (inb ? 1 : 0) : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (so[i] < 0) continue;
+            f32x4 v = sv[i];
+            if (P.in_mode == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            if (!(so[i] & 1)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(in_s + (so[i] >> 1)) = v;
+        }
     }
     __syncthreads();
     // ---- 5 rows x W pixels = 5 W / 16 pixel tiles, dealt to the four waves; a tile never crosses a row (W is a multiple of 16)
     const int ntiles = 5 * W / 16;
-    f32x4 acc[NT];
+    f32x4 acc[NT][CO_TILES];
     int pbase[NT];
     const FastDiv fW(W);
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-        acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < CO_TILES; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int t = min(wave + 4 * i, ntiles - 1);
         int py, px;
         fW.divmod(16 * t + c, py, px);
         pbase[i] = (py * PW + px) * CS + 4 * q;
     }
     const int nmine = (ntiles - wave + 3) >> 2;          // tiles of this wave
-    const f32x4 bv = P.bias ? ldg4(P.bias + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bv[CO_TILES];
+#pragma unroll
+    for (int j = 0; j < CO_TILES; ++j) bv[j] = P.bias ? ldg4(P.bias + 16 * j + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < 9; ++t) {
         const int toff = ((t / 3) * PW + (t % 3)) * CS;
-        const f32x4 b = *reinterpret_cast<const f32x4*>(w_s + c * WS + t * Ci + 4 * q);
-        u32x2 bh, bl;
-        if constexpr (SPLITR) bsplit4(b, bh, bl);
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {   // (clamped duplicate tiles of the last wave are computed and dropped: every accumulator index stays static)
-            const f32x4 a = *reinterpret_cast<const f32x4*>(in_s + pbase[i] + toff);
-            if constexpr (SPLITR) {
-                u32x2 ah, al;
-                bsplit4(a, ah, al);
-                acc[i] = mfma_bf16_k16(bh, al, acc[i]);
-                acc[i] = mfma_bf16_k16(bl, ah, acc[i]);
-                acc[i] = mfma_bf16_k16(bh, ah, acc[i]);
-            } else {
+        for (int g = 0; g < CI / 16; ++g) {
+            f32x4 b[CO_TILES];
+            u32x2 bh[CO_TILES], bl[CO_TILES];
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s4], a[s4], acc[i], 0, 0, 0);
+            for (int j = 0; j < CO_TILES; ++j) {
+                b[j] = *reinterpret_cast<const f32x4*>(w_s + (16 * j + c) * WS + t * CI + 16 * g + 4 * q);
+                if constexpr (SPLITR) bsplit4(b[j], bh[j], bl[j]);
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {   // (clamped duplicate tiles of the last waves are computed and dropped: every accumulator index stays static)
+                const f32x4 a = *reinterpret_cast<const f32x4*>(in_s + pbase[i] + toff + 16 * g);
+                if constexpr (SPLITR) {
+                    u32x2 ah, al;
+                    bsplit4(a, ah, al);
+#pragma unroll
+                    for (int j = 0; j < CO_TILES; ++j) {
+                        acc[i][j] = mfma_bf16_k16(bh[j], al, acc[i][j]);
+                        acc[i][j] = mfma_bf16_k16(bl[j], ah, acc[i][j]);
+                        acc[i][j] = mfma_bf16_k16(bh[j], ah, acc[i][j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                        for (int j = 0; j < CO_TILES; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][s4], a[s4], acc[i][j], 0, 0, 0);
+                }
             }
         }
     }
@@ -457,14 +502,18 @@ __device__ __forceinline__ void conv_u8_pool_body(const ConvArgs& P, float* lds)
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int t = wave + 4 * i;
-        if (i < nmine) *reinterpret_cast<f32x4*>(c_s + (16 * t + c) * OS + 4 * q) = acc[i] + bv;   // pixel 16 t + c of the 5 x W tile, channels 4 q .. 4 q + 3
+        if (i < nmine) {
+#pragma unroll
+            for (int j = 0; j < CO_TILES; ++j) *reinterpret_cast<f32x4*>(c_s + (16 * t + c) * OS + 16 * j + 4 * q) = acc[i][j] + bv[j];   // pixel 16 t + c, channels 16 j + 4 q ..
+        }
     }
     __syncthreads();
-    // ---- pool: 2 rows x W / 2 windows x 4 channel quads, one float4 per thread and round
+    // ---- pool: 2 rows x W / 2 windows x Co / 4 channel quads, one float4 per thread and round
     const int Wo = W >> 1, Ho = H >> 1;
-    const int nout = 2 * Wo * 4;
+    constexpr int CQ = Co / 4;
+    const int nout = 2 * Wo * CQ;
     for (int e = tid; e < nout; e += FQL_THREADS) {
-        const int cq = e & 3, r2 = e >> 2;
+        const int cq = e % CQ, r2 = e / CQ;
         const int orow = r2 >= Wo ? 1 : 0, ox = r2 - orow * Wo;
         const int oy = 2 * pr + orow;
         if (oy >= Ho) continue;
@@ -486,16 +535,24 @@ __device__ __forceinline__ void conv_u8_pool_body(const ConvArgs& P, float* lds)
         *reinterpret_cast<uchar4*>(P.parg + o) = make_uchar4((unsigned char)arg[0], (unsigned char)arg[1], (unsigned char)arg[2], (unsigned char)arg[3]);
     }
 }
-#define FQL_CONV_U8_POOL_LDS_FLOATS(W) ((7 * ((W) + 2) * 20 > 5 * (W) * 20 ? 7 * ((W) + 2) * 20 : 5 * (W) * 20) + 16 * (9 * 16 + 4))
-__global__ __launch_bounds__(FQL_THREADS, 3) void fql_conv3x3_u8_pool_kernel(const ConvArgs* __restrict__ tasks, int ntasks) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const ConvArgs& P = tasks[find_task(tasks, ntasks, blockIdx.x)];
-    if (P.W <= 64) conv_u8_pool_body<false, 5>(P, lds); else conv_u8_pool_body<false, 10>(P, lds);
+// LDS floats of the fused kernels: max(7 (W + 2) (Ci + 4), 5 W (Co + 4)) + Co (9 Ci + 4)
+#define FQL_CONV_POOL_LDS_FLOATS(W, Ci, Co) ((7 * ((W) + 2) * ((Ci) + 4) > 5 * (W) * ((Co) + 4) ? 7 * ((W) + 2) * ((Ci) + 4) : 5 * (W) * ((Co) + 4)) + (Co) * (9 * (Ci) + 4))
+#define FQL_CONV_U8_POOL_LDS_FLOATS(W) FQL_CONV_POOL_LDS_FLOATS(W, 16, 16)
+template <bool SPLITR>
+__device__ __forceinline__ void conv_pool_dispatch(const ConvArgs& P, float* lds) {
+    if (P.in_mode == 2) { if (P.W <= 64) conv_pool_body<true, 16, 1, SPLITR, 5>(P, lds); else conv_pool_body<true, 16, 1, SPLITR, 10>(P, lds); }
+    else if (P.Ci == 16 && P.Co == 32) { if (P.W <= 32) conv_pool_body<false, 16, 2, SPLITR, 3>(P, lds); else conv_pool_body<false, 16, 2, SPLITR, 5>(P, lds); }
+    else if (P.Ci == 32 && P.Co == 32) { if (P.W <= 32) conv_pool_body<false, 32, 2, SPLITR, 3>(P, lds); else conv_pool_body<false, 32, 2, SPLITR, 5>(P, lds); }
+    else if (P.Ci == 16 && P.Co == 16) { if (P.W <= 32) conv_pool_body<false, 16, 1, SPLITR, 3>(P, lds); else conv_pool_body<false, 16, 1, SPLITR, 5>(P, lds); }
+    else { if (P.W <= 32) conv_pool_body<false, 32, 1, SPLITR, 3>(P, lds); else conv_pool_body<false, 32, 1, SPLITR, 5>(P, lds); }
 }
-__global__ __launch_bounds__(FQL_THREADS, 3) void fql_conv3x3_u8_pool_split_kernel(const ConvArgs* __restrict__ tasks, int ntasks) {
+__global__ __launch_bounds__(FQL_THREADS, 3) void fql_conv3x3_pool_kernel(const ConvArgs* __restrict__ tasks, int ntasks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const ConvArgs& P = tasks[find_task(tasks, ntasks, blockIdx.x)];
-    if (P.W <= 64) conv_u8_pool_body<true, 5>(P, lds); else conv_u8_pool_body<true, 10>(P, lds);
+    conv_pool_dispatch<false>(tasks[find_task(tasks, ntasks, blockIdx.x)], lds);
+}
+__global__ __launch_bounds__(FQL_THREADS, 3) void fql_conv3x3_pool_split_kernel(const ConvArgs* __restrict__ tasks, int ntasks) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    conv_pool_dispatch<true>(tasks[find_task(tasks, ntasks, blockIdx.x)], lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1102,7 +1159,8 @@ struct ConvWprepTask {
     float* Wb;   // null: no data gradient needed (first convolution)
     int cin, cout, Ci;
     int split;   // precision = 2, float convolutions: Wf / Wb are bf16 hi / lo planes [rows][9 C / 2 + C / 4 words] (C = channels per tap) for
-                 // fql_conv3x3_split_kernel instead of the fp32 [rows][9 C + 4] image (the uint8 first layer keeps the fp32 image)
+                 // fql_conv3x3_split_kernel instead of the fp32 [rows][9 C + 4] image (the uint8 first layer keeps the fp32 image).
+                 // 1: both copies split; 2: only Wb (the forward copy stays fp32: a stack's first convolution fused with its max-pool splits in registers)
 };
 __device__ __forceinline__ void wprep_store_split(float* planes, int rows, int C, int row, int k, float v) {
     const int WSW = 9 * C / 2 + C / 4;
@@ -1121,7 +1179,8 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_conv_wprep_kernel(const ConvW
         const int o = e % T.cout, r = e / T.cout, c = r % T.cin, t = r / T.cin;
         const float v = T.K[e];
         if (T.split) {
-            wprep_store_split(T.Wf, T.cout, T.Ci, o, t * T.Ci + c, v);
+            if (T.split == 1) wprep_store_split(T.Wf, T.cout, T.Ci, o, t * T.Ci + c, v);
+            else T.Wf[(size_t)o * WSf + t * T.Ci + c] = v;
             if (T.Wb) wprep_store_split(T.Wb, T.cin, T.cout, c, (8 - t) * T.cout + o, v);
             continue;
         }

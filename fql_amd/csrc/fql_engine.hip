@@ -90,6 +90,7 @@ struct ConvL {
     int cin, cout;
     float *Wf = nullptr, *Wb = nullptr;   // LDS-layout copies refreshed by fql_conv_wprep_kernel at the start of each pass
     bool split = false;                   // precision = 2: the copies are bf16 hi / lo planes (fql_conv3x3_split_kernel)
+    bool pool_fused = false;              // a stack's first convolution that runs fused with the stack's max-pool (fp32 forward copy in both precisions)
 };
 struct EncStack {
     std::vector<ConvL> conv;  // conv[0] at the stack's input resolution, the rest after the 2x max-pool
@@ -161,7 +162,7 @@ struct Launch {
     size_t lds = 0;
     void* table = nullptr;  // device task table (GEMM/WGRAD/LNBWD)
     Op op;                  // arg-struct kernels
-    bool pool_fused = false; // OP_CONV_U8: the stack's max-pool runs inside the convolution kernel (fql_conv3x3_u8_pool_kernel)
+    bool pool_fused = false; // OP_CONV_U8: the stack's max-pool runs inside the convolution kernel (fql_conv3x3_pool_kernel)
     ChainArgs chain2{};     // OP_CHAIN variant E: second task of the launch (the other ensemble member)
     bool chain_pair = false;
     int lane = 0;
@@ -436,6 +437,19 @@ struct fql_engine {
             invalid("internal: target arena layout mismatch");
     }
 
+    // can the first convolution of a stack run fused with the stack's max-pool (fql_conv3x3_pool_kernel)?  first_stack: it reads the uint8 images
+    // Measured (visual update, one box): the uint8 layer fused +2.8 % (fp32) and more in bf16x3; the float layers of stacks 1 / 2 fused too: bf16x3 370.5 -> 373.9, fp32
+    // 311.7 -> 308.3 (their 5-row tiles redo a quarter of the rows, which fp32 MFMAs pay for) - so those are fused under precision = 2 only (FQL_FUSE_POOL_FLOAT=0/1 overrides).
+    bool pool_fusable(const EncStack& st, const ConvL& c, bool first_stack) const {
+        static const bool on = getenv("FQL_NO_FUSE_POOL") == nullptr;
+        static const int float_env = getenv("FQL_FUSE_POOL_FLOAT") ? atoi(getenv("FQL_FUSE_POOL_FLOAT")) : -1;
+        const bool on_float = float_env >= 0 ? float_env != 0 : cfg.precision == 2;
+        const int Ci = pad16c(c.cin);
+        if (!on || st.W % 16 || st.W < 16 || st.W > 128 || st.H % 2 || (c.cout != 16 && c.cout != 32)) return false;
+        if ((size_t)FQL_CONV_POOL_LDS_FLOATS(st.W, Ci, c.cout) * sizeof(float) > 65536) return false;
+        if (first_stack) return c.cout == 16 && Ci == 16 && 7 * st.W * c.cin <= 4 * 4 * FQL_THREADS && (st.W * c.cin) % 4 == 0;   // seven uint8 rows: <= 4 dwords per thread
+        return on_float && (Ci == 16 || Ci == 32) && Ci == c.cin && 7 * (st.W + 2) * (Ci / 4) <= 4 * FQL_THREADS;               // seven float rows: <= 4 float4 per thread
+    }
     // LDS-layout weight copies of every convolution + the task tables of fql_conv_wprep_kernel (needs P)
     void build_enc_weights() {
         if (!visual) return;
@@ -445,12 +459,15 @@ struct fql_engine {
             for (EncStack& st : encs[ei].stacks)
                 for (ConvL& c : st.conv) {
                     const int Ci = pad16c(c.cin);
+                    const bool first_stack = &st == &encs[ei].stacks[0];
                     // precision = 2: the float convolutions read pre-split bf16 hi / lo planes (slightly larger than the fp32 image)
                     const bool split = cfg.precision == 2 && !first && (Ci == 16 || Ci == 32) && (c.cout == 16 || c.cout == 32);
+                    // a stack's first convolution runs fused with the stack's max-pool and splits its fragments in registers: its forward copy stays fp32
+                    c.pool_fused = (&c == &st.conv[0]) && pool_fusable(st, c, first_stack);
                     c.Wf = dalloc(enc_allocs, std::max((size_t)c.cout * (9 * Ci + 4), (size_t)2 * c.cout * (9 * Ci / 2 + Ci / 4)));
                     c.Wb = first ? nullptr : dalloc(enc_allocs, std::max((size_t)c.cin * (9 * c.cout + 4), (size_t)2 * c.cin * (9 * c.cout / 2 + c.cout / 4)));   // no gradient into the images
                     c.split = split;
-                    tasks.push_back(ConvWprepTask{P + c.w, c.Wf, c.Wb, c.cin, c.cout, Ci, split ? 1 : 0});
+                    tasks.push_back(ConvWprepTask{P + c.w, c.Wf, c.Wb, c.cin, c.cout, Ci, split ? (c.pool_fused ? 2 : 1) : 0});
                     first = false;
                 }
             enc_nconv[ei] = (int)tasks.size();
@@ -766,10 +783,8 @@ struct fql_engine {
             const EncStack& st = en.stacks[s];
             EncBuf::St& bs = b.st[s];
             const int C = st.conv[0].cout, H2 = st.H / 2, W2 = st.W / 2;
-            // the uint8 first convolution and the stack's max-pool as one kernel: the pre-pool tensor (the largest write of the update) is never materialised
-            static const bool fuse_pool_env = getenv("FQL_NO_FUSE_POOL") == nullptr;
-            const bool fuse_pool = fuse_pool_env && s == 0 && C == 16 && st.W % 16 == 0 && st.W <= 128 && st.H % 2 == 0 && pad16c(st.conv[0].cin) == 16 &&
-                                   7 * st.W * st.conv[0].cin <= 4 * 4 * FQL_THREADS && (st.W * st.conv[0].cin) % 4 == 0;   // (seven input rows: <= 4 dwords per thread)
+            // a stack's first convolution and its max-pool as one kernel: the pre-pool tensor (for stack 0 the largest write of the update) is never materialised
+            const bool fuse_pool = st.conv[0].pool_fused;
             if (s == 0) emit_conv(pr, b.img, b.img, 2, n, st.H, st.W, st.conv[0], false, bs.c0, bs.c0, nullptr, nullptr, nullptr, nullptr, nullptr);
             else emit_conv(pr, x, x, 0, n, st.H, st.W, st.conv[0], false, bs.c0, bs.c0, nullptr, nullptr, nullptr, nullptr, nullptr);
             if (fuse_pool) {
@@ -1569,8 +1584,8 @@ struct fql_engine {
                             if (a.parg) {   // convolution + max-pool in one kernel: a workgroup per (image, pooled row pair)
                                 a.nwg = a.N * ((a.H + 3) / 4);
                                 L.pool_fused = true;
-                                L.lds = std::max(L.lds, (size_t)FQL_CONV_U8_POOL_LDS_FLOATS(a.W) * sizeof(float));
-                            }
+                                L.lds = std::max(L.lds, (size_t)FQL_CONV_POOL_LDS_FLOATS(a.W, a.Ci, a.Co) * sizeof(float));
+                            } else if (L.pool_fused) invalid("internal: a launch mixes fused and plain convolutions");
                             tile += a.nwg;
                             L.lds = std::max(L.lds, ((size_t)(a.R + 2) * (a.W + 2) * (a.Ci + 4) + (size_t)a.Co * (9 * a.Ci + 4)) * sizeof(float));
                             if (ty == OP_CONV && cfg.precision == 2) L.lds = std::max(L.lds, (size_t)FQL_CONV_SPLIT_LDS_WORDS(a.R, a.W, a.Ci, a.Co) * sizeof(float));
@@ -1845,13 +1860,15 @@ struct fql_engine {
                 FQL_LAUNCH(fql_conv_wprep_kernel, dim3(4, L.op.wprep_n), dim3(FQL_THREADS), 0, s, L.op.wprep_tasks);
                 break;
             case OP_CONV:
-                if (cfg.precision == 2) FQL_LAUNCH(fql_conv3x3_split_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
+                if (L.pool_fused && cfg.precision == 2) FQL_LAUNCH(fql_conv3x3_pool_split_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
+                else if (L.pool_fused) FQL_LAUNCH(fql_conv3x3_pool_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
+                else if (cfg.precision == 2) FQL_LAUNCH(fql_conv3x3_split_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
                 else
                 FQL_LAUNCH(fql_conv3x3_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
                 break;
             case OP_CONV_U8:
-                if (L.pool_fused && cfg.precision == 2) FQL_LAUNCH(fql_conv3x3_u8_pool_split_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
-                else if (L.pool_fused) FQL_LAUNCH(fql_conv3x3_u8_pool_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
+                if (L.pool_fused && cfg.precision == 2) FQL_LAUNCH(fql_conv3x3_pool_split_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
+                else if (L.pool_fused) FQL_LAUNCH(fql_conv3x3_pool_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
                 else if (cfg.precision == 2 && u8_split) FQL_LAUNCH(fql_conv3x3_u8_split_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
                 else
                 FQL_LAUNCH(fql_conv3x3_u8_kernel, dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const ConvArgs*)L.table, L.ntasks);
