@@ -61,6 +61,9 @@ int main() {
         std::vector<float> r = host(C0r, (size_t)M * H), f((size_t)M * H);
         for (int m = 0; m < M; ++m) for (int n = 0; n < H; ++n) f[((size_t)(m / 4) * H + n) * 4 + (m & 3)] = r[(size_t)m * H + n];
         CK(hipMalloc(&C0, (size_t)M * H * 4)); CK(hipMemcpy(C0, f.data(), (size_t)M * H * 4, hipMemcpyHostToDevice));
+        // the split kernel's layout (GF_C_FRAGT): [M/16][H/16][q = (n % 16) / 4][c = m % 16][n % 4]
+        for (int m = 0; m < M; ++m) for (int n = 0; n < H; ++n) f[(((size_t)(m / 16) * (H / 16) + n / 16) * 64 + ((n % 16) / 4) * 16 + m % 16) * 4 + n % 4] = r[(size_t)m * H + n];
+        CK(hipMemcpy(C0r, f.data(), (size_t)M * H * 4, hipMemcpyHostToDevice));
     }
     float* W = dev((size_t)H * H, 3, 0.08f);
     float* W0 = dev((size_t)48 * H, 4, 0.2f);        // layer-0 kernel rows (obs | act | t | pad), ld = H

@@ -419,7 +419,7 @@ __global__ __launch_bounds__(FQL_CHAIN_THREADS, (V == 0 ? FQL_CHAIN_SPLIT_WAVES_
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
             const int ct = wave + 8 * t;
-            cacc[t] = ldg4(P.A + (size_t)(row0 + c) * H + 16 * ct + 4 * q);   // C0 row-major: row c, columns 16 ct + 4q .. + 3 (layer 0 runs transposed)
+            cacc[t] = ldg4(P.A + (((size_t)(row0 >> 4) * (H / 16) + ct) * 64 + 16 * q + c) * 4);   // C0 in GF_C_FRAGT layout: row c, columns 16 ct + 4q .. + 3, 1 KB contiguous per tile
             wf[t] = ldg4u(reinterpret_cast<const unsigned*>(P.W0f) + ((size_t)q * H + 16 * ct + c) * 4);
         }
         {   // a_s = a_{s-1} + (sum of head partials + head bias) / flow_steps: two threads per element, fixed order

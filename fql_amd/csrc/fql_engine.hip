@@ -1146,7 +1146,7 @@ struct fql_engine {
             op.type = OP_GEMM;
             GemmTask& t = op.gemm;
             t.A = X_e0; t.lda = l0.in_p; t.B = P + l0.w; t.ldb = l0.out_p; t.bias = P + l0.b; t.C = C0; t.ldc = l0.out_p;
-            t.M = B; t.N = l0.out_p; t.K = l0.in_p; t.flags = GF_BIAS | (cfg.precision == 2 ? 0 : GF_C_FRAG);   // the split chain reads C0 row-major
+            t.M = B; t.N = l0.out_p; t.K = l0.in_p; t.flags = GF_BIAS | (cfg.precision == 2 ? GF_C_FRAGT : GF_C_FRAG);   // the split chain runs layer 0 transposed: C0 in the transposed-tile layout
             op.reads = {X_e0, t.B};
             op.writes = {C0};
             push(pr, op);

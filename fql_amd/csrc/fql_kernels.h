@@ -146,6 +146,8 @@ enum : int {
                              // aux = a of the last step [M, i0], aux2 = partials [ln_width][M][i0], eb = head bias, f1 = 1 / flow_steps; evp = target OUT (column tile 0)
     GF_RELUGRAD = 1 << 14,   // epilogue: C = (Zprev > 0) ? acc : 0  (dgrad through the encoder's final ReLU, utils/encoders.py:92)
     GF_LN_PART = 1 << 10,   // gemm64 epilogue: per-row (sum, sum sq) of this 64-column tile -> aux[row][i1 tiles][2]
+    GF_C_FRAGT = 1 << 16,   // gemm16 epilogue: C (+ bias) in the layout a TRANSPOSED 16 x 16 accumulator tile reads as one dwordx4 per lane, 1 KB contiguous
+                            // per tile: [M/16][N/16][q = (n % 16) / 4][c = m % 16][n % 4] (fql_chain_split_kernel variant A: lane (c, q) owns row c, columns 4 q ..)
     GF_C_FRAG = 1 << 18,    // gemm16 epilogue: C (+ bias) stored in accumulator-fragment-major layout [M/4][N][4] (one dwordx4 per lane;
                             // read back as one dwordx4 per MFMA tile by fql_chain_kernel variant A)
 };
@@ -745,6 +747,16 @@ __device__ __forceinline__ void gemm16_body(const GemmTask& T, float* lds) {
 
     // ---- epilogue. C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
     const int n = n0 + c;
+    if (flags & GF_C_FRAGT) {   // this lane holds rows 4 q + i of column n: four 4-byte stores (written once per update, read ten times)
+#pragma unroll
+        for (int rt = 0; rt < TMT; ++rt) {
+            const int m0 = row0 + 16 * rt;
+            float* tb = T.C + ((size_t)(m0 >> 4) * (T.ldc >> 4) + (n >> 4)) * 256 + ((n & 15) >> 2) * 64 + (n & 3);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stg(tb + (4 * q + i) * 4, acc[rt][i] + bias);
+        }
+        return;
+    }
     if (flags & GF_C_FRAG) {
 #pragma unroll
         for (int rt = 0; rt < TMT; ++rt) {
