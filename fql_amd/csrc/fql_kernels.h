@@ -1563,114 +1563,123 @@ __global__ __launch_bounds__(FQL_THREADS, 2) void fql_gemm64_kernel(const GemmTa
 // ------------------------------------------------------------------------------------------------
 // K9 wgrad: dW[Kin, N] = X^T dZ (contraction over the batch), db[n] = sum_m dZ[m, n]
 //   implied by jax.grad, utils/flax_utils.py:137.
-// Workgroup tile 16 (Kin) x 64 (N).  The 4 waves split the batch (contraction) dimension, each holds
-// four 16x16 accumulators that share one X^T fragment per MFMA step (5 dword loads per 4 MFMAs),
-// loads are issued a chunk of 8 steps (40 VGPRs) ahead; partial tiles meet in LDS and wave t
-// finalises column tile t.  Summation order is fixed, so gradients are bitwise reproducible.
+// Workgroup tile 16 (Kin) x 64 (N).  The 4 waves split the batch (contraction) dimension, each holds four 16x16 accumulators
+// that share one X^T fragment per MFMA step.  The product is transposed (dZ is the A operand) and the A rows are PERMUTED: lane
+// (c, q) loads the 16 bytes dZ[m][n0 + 4 c .. + 3] - the 16 lanes of a row group read one whole 256-byte tile row, full 128-byte
+// lines instead of four 64-byte segments per dword load - and feeds component t to accumulator t, so that row i of accumulator t
+// is column n0 + 4 i + t.  A lane then owns dW[k0 + c][n0 + 16 q + 4 r + t] (r = accumulator register): sixteen consecutive
+// columns.  Loads are issued a chunk of 8 steps (40 VGPRs) ahead; partial tiles meet in LDS and thread (wave w, lane) finalises
+// register r = w of all four accumulators = one 16-byte store.  Summation order is fixed: gradients are bitwise reproducible.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wgrad_load_chunk(float (&a)[8], float (&b)[32], const float* xp, const float* zp,
-                                                 size_t sx, size_t sz, int cnt, int ntv) {
+__device__ __forceinline__ void wgrad_load_chunk(float (&a)[8], f32x4 (&b)[8], const float* xp, const float* zp,
+                                                 size_t sx, size_t sz, int cnt, bool zv) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const bool v = i < cnt;
         a[i] = v ? ldg(xp + i * sx) : 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) b[4 * i + t] = (v && t < ntv) ? ldg(zp + i * sz + 16 * t) : 0.f;
+        b[i] = (v && zv) ? ldg4(zp + i * sz) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
-// lds: 4 * 4 * 64 * 4 + 4 * 64 floats.  bid = block index inside the wgrad task space of the launch.
-__device__ __forceinline__ void wgrad_body(const WgradTask& T, int bid, float* lds) {
-    float* red = lds;                    // [wave][tile][lane] float4
+// the reduction over the 4 waves and the stores, shared by the fp32 and the split body
+__device__ __forceinline__ void wgrad_finish(const WgradTask& T, float* lds, const f32x4 (&acc)[4], const float (&bs)[4], int tk, int k0, int n0, int ntv) {
+    float* red = lds;                    // [wave][accumulator][lane] float4
     float (*redb)[64] = reinterpret_cast<float (*)[64]>(lds + 4 * 4 * 64 * 4);
-    const int local = bid - T.tile0;
-    const int tk = sdiv(local, frcp(T.ntn)), tn = local - tk * T.ntn;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 15, q = lane >> 4;
-    const int k0 = tk * 16, n0 = tn * 64;
-    const int ntv = min(4, (T.N - n0) >> 4);  // valid 16-column tiles in this workgroup
-    const int steps = T.M >> 4;               // MFMA steps (4 batch rows each) per wave
-    const size_t sx = (size_t)4 * T.ldx, sz = (size_t)4 * T.ldz;
-    const float* __restrict__ xp = T.X + (size_t)(4 * wave * steps + q) * T.ldx + k0 + c;   // A[i = kin][k = m]
-    const float* __restrict__ zp = T.dZ + (size_t)(4 * wave * steps + q) * T.ldz + n0 + c;  // B[k = m][j = n]
-    f32x4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bs[4] = {0.f, 0.f, 0.f, 0.f};
-    float a0[8], b0[32], a1[8], b1[32];
-    auto mma = [&](const float(&a)[8], const float(&b)[32]) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                bs[t] += b[4 * i + t];
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[4 * i + t], a[i], acc[t], 0, 0, 0);   // transposed: a lane owns dW[k0 + c][n0 + 16 t + 4 q .. + 3]
-            }
-    };
-    wgrad_load_chunk(a0, b0, xp, zp, sx, sz, steps, ntv);
-    for (int s = 0; s < steps; s += 16) {
-        if (s + 8 < steps) wgrad_load_chunk(a1, b1, xp + (s + 8) * sx, zp + (s + 8) * sz, sx, sz, steps - s - 8, ntv);
-        mma(a0, b0);
-        if (s + 8 < steps) {
-            if (s + 16 < steps) wgrad_load_chunk(a0, b0, xp + (s + 16) * sx, zp + (s + 16) * sz, sx, sz, steps - s - 16, ntv);
-            mma(a1, b1);
-        }
-    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         *reinterpret_cast<f32x4*>(&red[((wave * 4 + t) * 64 + lane) * 4]) = acc[t];
         float v = bs[t];
         v += __shfl_xor(v, 16);
         v += __shfl_xor(v, 32);
-        if (q == 0) redb[wave][16 * t + c] = v;
+        if (q == 0) redb[wave][4 * c + t] = v;
     }
     __syncthreads();
-    if (wave < ntv) {
-        f32x4 r = *reinterpret_cast<const f32x4*>(&red[((0 * 4 + wave) * 64 + lane) * 4]);
+    if (4 * q + wave < 4 * ntv) {
+        f32x4 r;
 #pragma unroll
-        for (int w = 1; w < 4; ++w) r += *reinterpret_cast<const f32x4*>(&red[((w * 4 + wave) * 64 + lane) * 4]);
-        stg4(T.dW + (size_t)(k0 + c) * T.ldw + n0 + 16 * wave + 4 * q, r);   // one 16-byte store per lane (the product is transposed)
-        if (tk == 0 && T.db && q == 0) {
-            const int j = 16 * wave + c;
-            T.db[n0 + j] = redb[0][j] + redb[1][j] + redb[2][j] + redb[3][j];
+        for (int t = 0; t < 4; ++t) {
+            float v = red[((0 * 4 + t) * 64 + lane) * 4 + wave];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) v += red[((w * 4 + t) * 64 + lane) * 4 + wave];
+            r[t] = v;
         }
+        stg4(T.dW + (size_t)(k0 + c) * T.ldw + n0 + 16 * q + 4 * wave, r);
     }
+    if (tk == 0 && T.db && wave == 0 && lane < 16 * ntv) T.db[n0 + lane] = redb[0][lane] + redb[1][lane] + redb[2][lane] + redb[3][lane];
 }
-#define FQL_WGRAD_LDS_FLOATS (4 * 4 * 64 * 4 + 4 * 64)
-// precision = 2 weight gradient: same tile geometry, LDS reduction and summation order over waves.  The 8 batch rows a lane holds
-// per chunk for X^T and for each dZ column tile are exactly one 16x16x32 operand each (the k order inside an MFMA step is free as
-// long as both operands share it), so a chunk is split in registers and multiplied with 3 x 4 bf16 MFMAs instead of 32 fp32 ones;
-// db stays an fp32 column sum.  Loads are branch-free (out-of-range steps / column tiles re-read a valid address and are zeroed).
-__device__ __forceinline__ void wgrad_split_body(const WgradTask& T, int bid, float* lds) {
-    float* red = lds;                    // [wave][tile][lane] float4
-    float (*redb)[64] = reinterpret_cast<float (*)[64]>(lds + 4 * 4 * 64 * 4);
+// lds: 4 * 4 * 64 * 4 + 4 * 64 floats.  bid = block index inside the wgrad task space of the launch.
+__device__ __forceinline__ void wgrad_body(const WgradTask& T, int bid, float* lds) {
     const int local = bid - T.tile0;
     const int tk = sdiv(local, frcp(T.ntn)), tn = local - tk * T.ntn;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 15, q = lane >> 4;
     const int k0 = tk * 16, n0 = tn * 64;
     const int ntv = min(4, (T.N - n0) >> 4);  // valid 16-column tiles in this workgroup
+    const bool zv = c < 4 * ntv;              // this lane's four dZ columns exist
     const int steps = T.M >> 4;               // MFMA steps (4 batch rows each) per wave
     const size_t sx = (size_t)4 * T.ldx, sz = (size_t)4 * T.ldz;
-    const float* __restrict__ xp = T.X + (size_t)(4 * wave * steps + q) * T.ldx + k0 + c;   // A[i = kin][k = m]
-    const float* __restrict__ zp = T.dZ + (size_t)(4 * wave * steps + q) * T.ldz + n0 + c;  // B[k = m][j = n]
-    int toff[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) toff[t] = 16 * min(t, ntv - 1);
+    const float* __restrict__ xp = T.X + (size_t)(4 * wave * steps + q) * T.ldx + k0 + c;       // B[k = m][j = kin]
+    const float* __restrict__ zp = T.dZ + (size_t)(4 * wave * steps + q) * T.ldz + n0 + 4 * c;  // A[i][k = m], i <-> columns n0 + 4 i + t
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
-    float a0[8], b0[32], a1[8], b1[32];
-    auto load = [&](float (&a)[8], float (&b)[32], int s0) {
+    float a0[8], a1[8];
+    f32x4 b0[8], b1[8];
+    auto mma = [&](const float(&a)[8], const f32x4(&b)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                bs[t] += b[i][t];
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[i][t], a[i], acc[t], 0, 0, 0);
+            }
+    };
+    wgrad_load_chunk(a0, b0, xp, zp, sx, sz, steps, zv);
+    for (int s = 0; s < steps; s += 16) {
+        if (s + 8 < steps) wgrad_load_chunk(a1, b1, xp + (s + 8) * sx, zp + (s + 8) * sz, sx, sz, steps - s - 8, zv);
+        mma(a0, b0);
+        if (s + 8 < steps) {
+            if (s + 16 < steps) wgrad_load_chunk(a0, b0, xp + (s + 16) * sx, zp + (s + 16) * sz, sx, sz, steps - s - 16, zv);
+            mma(a1, b1);
+        }
+    }
+    wgrad_finish(T, lds, acc, bs, tk, k0, n0, ntv);
+}
+#define FQL_WGRAD_LDS_FLOATS (4 * 4 * 64 * 4 + 4 * 64)
+// precision = 2 weight gradient: same tile geometry, operand permutation, LDS reduction and summation order over waves.  The 8
+// batch rows a lane holds per chunk for X^T and for each dZ column are exactly one 16x16x32 operand each (the k order inside an
+// MFMA step is free as long as both operands share it), so a chunk is split in registers and multiplied with 3 x 4 bf16 MFMAs
+// instead of 32 fp32 ones; db stays an fp32 column sum.  Loads are branch-free (out-of-range steps / columns re-read a valid
+// address and are zeroed).
+__device__ __forceinline__ void wgrad_split_body(const WgradTask& T, int bid, float* lds) {
+    const int local = bid - T.tile0;
+    const int tk = sdiv(local, frcp(T.ntn)), tn = local - tk * T.ntn;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = lane & 15, q = lane >> 4;
+    const int k0 = tk * 16, n0 = tn * 64;
+    const int ntv = min(4, (T.N - n0) >> 4);  // valid 16-column tiles in this workgroup
+    const bool zv = c < 4 * ntv;
+    const int steps = T.M >> 4;               // MFMA steps (4 batch rows each) per wave
+    const size_t sx = (size_t)4 * T.ldx, sz = (size_t)4 * T.ldz;
+    const float* __restrict__ xp = T.X + (size_t)(4 * wave * steps + q) * T.ldx + k0 + c;
+    const float* __restrict__ zp = T.dZ + (size_t)(4 * wave * steps + q) * T.ldz + n0 + min(4 * c, 16 * ntv - 4);
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    float a0[8], a1[8];
+    f32x4 b0[8], b1[8];
+    auto load = [&](float (&a)[8], f32x4 (&b)[8], int s0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int st = min(s0 + i, steps - 1);
             a[i] = ldg(xp + st * sx);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) b[4 * i + t] = ldg(zp + st * sz + toff[t]);
+            b[i] = ldg4(zp + st * sz);
         }
     };
-    auto mma = [&](const float (&a)[8], const float (&b)[32], int s0) {
+    auto mma = [&](const float (&a)[8], const f32x4 (&b)[8], int s0) {
         float av[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) av[i] = (s0 + i < steps) ? a[i] : 0.f;   // zero X rows: the products of a clamped step vanish
@@ -1683,13 +1692,13 @@ __device__ __forceinline__ void wgrad_split_body(const WgradTask& T, int bid, fl
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 unsigned h, l;
-                const float b0v = (s0 + 2 * i < steps && t < ntv) ? b[8 * i + t] : 0.f;
-                const float b1v = (s0 + 2 * i + 1 < steps && t < ntv) ? b[8 * i + 4 + t] : 0.f;
+                const float b0v = (s0 + 2 * i < steps && zv) ? b[2 * i][t] : 0.f;
+                const float b1v = (s0 + 2 * i + 1 < steps && zv) ? b[2 * i + 1][t] : 0.f;
                 bs[t] += b0v + b1v;
                 bsplit2(b0v, b1v, h, l);
                 bh[i] = h; bl[i] = l;
             }
-            acc[t] = mfma_bf16(bh, al, acc[t]);   // transposed product (see wgrad_body): dW[k0 + c][n0 + 16 t + 4 q .. + 3]
+            acc[t] = mfma_bf16(bh, al, acc[t]);
             acc[t] = mfma_bf16(bl, ah, acc[t]);
             acc[t] = mfma_bf16(bh, ah, acc[t]);
             __builtin_amdgcn_sched_barrier(0);   // keeps the compiler from hoisting every split in front of the MFMAs (spills)
@@ -1704,25 +1713,7 @@ __device__ __forceinline__ void wgrad_split_body(const WgradTask& T, int bid, fl
             mma(a1, b1, s + 8);
         }
     }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        *reinterpret_cast<f32x4*>(&red[((wave * 4 + t) * 64 + lane) * 4]) = acc[t];
-        float v = bs[t];
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (q == 0) redb[wave][16 * t + c] = v;
-    }
-    __syncthreads();
-    if (wave < ntv) {
-        f32x4 r = *reinterpret_cast<const f32x4*>(&red[((0 * 4 + wave) * 64 + lane) * 4]);
-#pragma unroll
-        for (int w = 1; w < 4; ++w) r += *reinterpret_cast<const f32x4*>(&red[((w * 4 + wave) * 64 + lane) * 4]);
-        stg4(T.dW + (size_t)(k0 + c) * T.ldw + n0 + 16 * wave + 4 * q, r);   // one 16-byte store per lane (the product is transposed)
-        if (tk == 0 && T.db && q == 0) {
-            const int j = 16 * wave + c;
-            T.db[n0 + j] = redb[0][j] + redb[1][j] + redb[2][j] + redb[3][j];
-        }
-    }
+    wgrad_finish(T, lds, acc, bs, tk, k0, n0, ntv);
 }
 __global__ __launch_bounds__(FQL_THREADS) void fql_wgrad_kernel(const WgradTask* __restrict__ tasks, int ntasks) {
     __shared__ __attribute__((aligned(16))) float lds_w[FQL_WGRAD_LDS_FLOATS];
