@@ -1790,19 +1790,20 @@ __device__ __forceinline__ void lnbwd_body(const LnBwdTask& T, int bid, float (*
         float sg = 0.f, sb = 0.f;
         if (col < T.width) {
             const float wc = SYN ? ldg(T.wq + (size_t)col * T.ldw) : 0.f;
-            for (int m0 = rg; m0 < T.M; m0 += 64) {  // 4 rows per thread in flight
-                float mn[4], rs[4], dv[4], zv[4];
+            for (int m0 = rg; m0 < T.M; m0 += 256) {  // 16 rows per thread in flight: one round trip at M = 256 (was four rounds of 4 rows)
+                f32x2 st[16];
+                float dv[16], zv[16];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     const int m = min(m0 + 16 * u, T.M - 1);
-                    mn[u] = ldg(T.stats + 2 * m); rs[u] = ldg(T.stats + 2 * m + 1);
+                    st[u] = *(const FQL_GAS f32x2*)(T.stats + 2 * m);
                     dv[u] = SYN ? ldg(T.dq + (size_t)m * T.ldq) * wc : ldg(T.dY + (size_t)m * T.ld + col);
                     zv[u] = ldg(T.Gv + (size_t)m * T.ld + col);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     if (m0 + 16 * u < T.M) {
-                        const float xh = (zv[u] - mn[u]) * rs[u];
+                        const float xh = (zv[u] - st[u][0]) * st[u][1];
                         sg += dv[u] * xh; sb += dv[u];
                     }
                 }
