@@ -1503,11 +1503,12 @@ struct fql_engine {
                     }
                     L.tile_w = tile;
                     std::vector<WgradTask> tw;
+                    const int wkt = cfg.precision == 2 ? FQL_WGRAD_KT_SPLIT : FQL_WGRAD_KT;   // weight-gradient tile height of the body this launch runs
                     int tilew = 0;
                     for (const Op* o : selw) {
                         WgradTask t = o->wgrad;
                         t.ntn = (t.N + 63) / 64; t.tile0 = tilew;
-                        tilew += (t.Kin / 16) * t.ntn;
+                        tilew += ((t.Kin + wkt - 1) / wkt) * t.ntn;
                         tw.push_back(t);
                     }
                     L.tile_l = L.tile_w + tilew;
@@ -1531,11 +1532,12 @@ struct fql_engine {
                     }
                     L.grid = L.tile_m + (int)tmisc.size();
                     L.ntasks = (int)tg.size(); L.n_w = (int)tw.size(); L.n_l = (int)tl.size();
-                    L.lds = sizeof(float) * (tg.empty() ? (size_t)FQL_WGRAD_LDS_FLOATS
+                    const size_t wlds = cfg.precision == 2 ? (size_t)(4 * 4 * 64 * 4 + 4 * 64) : (size_t)FQL_WGRAD_LDS_FLOATS;   // 16- / 32-input tiles
+                    L.lds = sizeof(float) * (tg.empty() ? wlds
                                              : ri == 2 ? (size_t)(2 * (32 * ri + 64) * 68 + 256)
                                              : cfg.precision == 2 ? (size_t)FQL_TILE_SPLIT_LDS_FLOATS(nj)
                                              : nj == 1 ? (size_t)(2 * 32 * 68 + 2 * 64 * 36 + 128) : (size_t)(2 * 32 * 68 + 2 * 64 * 68 + 128));
-                    L.lds = std::max(L.lds, sizeof(float) * (size_t)((selw.empty() ? 0 : FQL_WGRAD_LDS_FLOATS)));
+                    L.lds = std::max(L.lds, sizeof(float) * (selw.empty() ? (size_t)0 : wlds));
                     auto up = [&](const void* src, size_t bytes) -> void* {
                         void* d = dalloc(owner, bytes / sizeof(float) + 4);
                         if (bytes) HIP_CHECK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
@@ -1684,7 +1686,7 @@ struct fql_engine {
                         WgradTask t = o->wgrad;
                         t.ntn = (t.N + 63) / 64;
                         t.tile0 = tile;
-                        tile += (t.Kin / 16) * t.ntn;
+                        tile += ((t.Kin + FQL_WGRAD_KT - 1) / FQL_WGRAD_KT) * t.ntn;
                         tb.push_back(t);
                     }
                     L.table = dalloc(owner, tb.size() * sizeof(WgradTask) / sizeof(float) + 4);

@@ -1563,111 +1563,126 @@ __global__ __launch_bounds__(FQL_THREADS, 2) void fql_gemm64_kernel(const GemmTa
 // ------------------------------------------------------------------------------------------------
 // K9 wgrad: dW[Kin, N] = X^T dZ (contraction over the batch), db[n] = sum_m dZ[m, n]
 //   implied by jax.grad, utils/flax_utils.py:137.
-// Workgroup tile 16 (Kin) x 64 (N).  The 4 waves split the batch (contraction) dimension, each holds four 16x16 accumulators
-// that share one X^T fragment per MFMA step.  The product is transposed (dZ is the A operand) and the A rows are PERMUTED: lane
-// (c, q) loads the 16 bytes dZ[m][n0 + 4 c .. + 3] - the 16 lanes of a row group read one whole 256-byte tile row, full 128-byte
-// lines instead of four 64-byte segments per dword load - and feeds component t to accumulator t, so that row i of accumulator t
-// is column n0 + 4 i + t.  A lane then owns dW[k0 + c][n0 + 16 q + 4 r + t] (r = accumulator register): sixteen consecutive
-// columns.  Loads are issued a chunk of 8 steps (40 VGPRs) ahead; partial tiles meet in LDS and thread (wave w, lane) finalises
-// register r = w of all four accumulators = one 16-byte store.  Summation order is fixed: gradients are bitwise reproducible.
+// Workgroup tile 32 (Kin) x 64 (N).  The 4 waves split the batch (contraction) dimension, each holds 2 x 4 16x16 accumulators.
+// The product is transposed (dZ is the A operand, X the B operand) and BOTH operands' free indices are PERMUTED so that a lane
+// loads whole vectors: lane (c, q) loads the 16 bytes dZ[m][n0 + 4 c .. + 3] - the 16 lanes of a row group read one whole
+// 256-byte tile row, full 128-byte lines instead of four 64-byte segments per dword load - and feeds component t to the
+// accumulators [.][t] (row i of accumulator t is column n0 + 4 i + t); it loads the 8 bytes X[m][k0 + 2 c .. + 1] and feeds
+// component u to the accumulators [u][.] (column j of accumulator u is input k0 + 2 j + u).  Two loads feed eight MFMAs.
+// A lane then owns dW[k0 + 2 c + u][n0 + 16 q + 4 r + t] (r = accumulator register): sixteen consecutive columns of two rows.
+// Loads are issued a chunk of 8 steps (48 VGPRs) ahead; partial tiles meet in LDS and thread (wave w, lane) finalises register
+// r = w of the eight accumulators = two 16-byte stores.  Summation order is fixed: gradients are bitwise reproducible.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wgrad_load_chunk(float (&a)[8], f32x4 (&b)[8], const float* xp, const float* zp,
-                                                 size_t sx, size_t sz, int cnt, bool zv) {
+#define FQL_WGRAD_KT 32   // inputs (rows of dW) per workgroup tile; the engine counts tiles with it
+#define FQL_WGRAD_LDS_FLOATS (4 * 8 * 64 * 4 + 4 * 64)
+// (no per-lane validity here: a lane whose columns / inputs lie outside the matrix reads a clamped, valid address and computes values that only
+// reach accumulator rows / columns the finish never stores)
+__device__ __forceinline__ void wgrad_load_chunk(f32x2 (&a)[8], f32x4 (&b)[8], const float* xp, const float* zp, unsigned xo, unsigned zo, size_t sx, size_t sz, int cnt) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const bool v = i < cnt;
-        a[i] = v ? ldg(xp + i * sx) : 0.f;
-        b[i] = (v && zv) ? ldg4(zp + i * sz) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool v = i < cnt;   // wave-uniform
+        a[i] = v ? *(const FQL_GAS f32x2*)(xp + i * sx + xo) : f32x2{0.f, 0.f};
+        b[i] = v ? ldg4(zp + i * sz + zo) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 // the reduction over the 4 waves and the stores, shared by the fp32 and the split body
-__device__ __forceinline__ void wgrad_finish(const WgradTask& T, float* lds, const f32x4 (&acc)[4], const float (&bs)[4], int tk, int k0, int n0, int ntv) {
-    float* red = lds;                    // [wave][accumulator][lane] float4
-    float (*redb)[64] = reinterpret_cast<float (*)[64]>(lds + 4 * 4 * 64 * 4);
+template <int NU>   // NU inputs per lane: the tile is 16 NU inputs high
+__device__ __forceinline__ void wgrad_finish(const WgradTask& T, float* lds, const f32x4 (&acc)[NU][4], const float (&bs)[4], int tk, int k0, int n0,
+                                             int ntv, bool xv) {
+    float* red = lds;                    // [wave][accumulator u, t][lane] float4
+    float (*redb)[64] = reinterpret_cast<float (*)[64]>(lds + 4 * 4 * NU * 64 * 4);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 15, q = lane >> 4;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        *reinterpret_cast<f32x4*>(&red[((wave * 4 + t) * 64 + lane) * 4]) = acc[t];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) *reinterpret_cast<f32x4*>(&red[((wave * 4 * NU + 4 * u + t) * 64 + lane) * 4]) = acc[u][t];
         float v = bs[t];
         v += __shfl_xor(v, 16);
         v += __shfl_xor(v, 32);
         if (q == 0) redb[wave][4 * c + t] = v;
     }
     __syncthreads();
-    if (4 * q + wave < 4 * ntv) {
-        f32x4 r;
+    if (xv && 4 * q + wave < 4 * ntv) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float v = red[((0 * 4 + t) * 64 + lane) * 4 + wave];
+        for (int u = 0; u < NU; ++u) {
+            f32x4 r;
 #pragma unroll
-            for (int w = 1; w < 4; ++w) v += red[((w * 4 + t) * 64 + lane) * 4 + wave];
-            r[t] = v;
+            for (int t = 0; t < 4; ++t) {
+                float v = red[((0 * 4 * NU + 4 * u + t) * 64 + lane) * 4 + wave];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) v += red[((w * 4 * NU + 4 * u + t) * 64 + lane) * 4 + wave];
+                r[t] = v;
+            }
+            stg4(T.dW + (size_t)(k0 + NU * c + u) * T.ldw + n0 + 16 * q + 4 * wave, r);
         }
-        stg4(T.dW + (size_t)(k0 + c) * T.ldw + n0 + 16 * q + 4 * wave, r);
     }
     if (tk == 0 && T.db && wave == 0 && lane < 16 * ntv) T.db[n0 + lane] = redb[0][lane] + redb[1][lane] + redb[2][lane] + redb[3][lane];
 }
-// lds: 4 * 4 * 64 * 4 + 4 * 64 floats.  bid = block index inside the wgrad task space of the launch.
+// lds: FQL_WGRAD_LDS_FLOATS floats.  bid = block index inside the wgrad task space of the launch.
 __device__ __forceinline__ void wgrad_body(const WgradTask& T, int bid, float* lds) {
     const int local = bid - T.tile0;
     const int tk = sdiv(local, frcp(T.ntn)), tn = local - tk * T.ntn;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave-uniform row offsets stay in SGPRs
     const int c = lane & 15, q = lane >> 4;
-    const int k0 = tk * 16, n0 = tn * 64;
+    const int k0 = tk * FQL_WGRAD_KT, n0 = tn * 64;
     const int ntv = min(4, (T.N - n0) >> 4);  // valid 16-column tiles in this workgroup
-    const bool zv = c < 4 * ntv;              // this lane's four dZ columns exist
+    const bool xv = k0 + 2 * c < T.Kin;       // this lane's two inputs exist (Kin is a multiple of 16)
     const int steps = T.M >> 4;               // MFMA steps (4 batch rows each) per wave
     const size_t sx = (size_t)4 * T.ldx, sz = (size_t)4 * T.ldz;
-    const float* __restrict__ xp = T.X + (size_t)(4 * wave * steps + q) * T.ldx + k0 + c;       // B[k = m][j = kin]
-    const float* __restrict__ zp = T.dZ + (size_t)(4 * wave * steps + q) * T.ldz + n0 + 4 * c;  // A[i][k = m], i <-> columns n0 + 4 i + t
-    f32x4 acc[4];
+    // uniform base (SGPR pair) + 32-bit lane offset: every load of a chunk shares one offset register
+    const float* __restrict__ xp = T.X + (size_t)(4 * wave * steps) * T.ldx;    // B[k = m][j], j <-> inputs k0 + 2 j + u
+    const float* __restrict__ zp = T.dZ + (size_t)(4 * wave * steps) * T.ldz;   // A[i][k = m], i <-> columns n0 + 4 i + t
+    const unsigned xo = (unsigned)(q * T.ldx + min(k0 + 2 * c, T.Kin - 2)), zo = (unsigned)(q * T.ldz + n0 + min(4 * c, 16 * ntv - 4));
+    f32x4 acc[2][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 4; ++t) acc[0][t] = acc[1][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
-    float a0[8], a1[8];
+    f32x2 a0[8], a1[8];
     f32x4 b0[8], b1[8];
-    auto mma = [&](const float(&a)[8], const f32x4(&b)[8]) {
+    auto mma = [&](const f32x2(&a)[8], const f32x4(&b)[8]) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 bs[t] += b[i][t];
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[i][t], a[i], acc[t], 0, 0, 0);
+                acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[i][t], a[i][0], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[i][t], a[i][1], acc[1][t], 0, 0, 0);
             }
     };
-    wgrad_load_chunk(a0, b0, xp, zp, sx, sz, steps, zv);
+    wgrad_load_chunk(a0, b0, xp, zp, xo, zo, sx, sz, steps);
     for (int s = 0; s < steps; s += 16) {
-        if (s + 8 < steps) wgrad_load_chunk(a1, b1, xp + (s + 8) * sx, zp + (s + 8) * sz, sx, sz, steps - s - 8, zv);
+        if (s + 8 < steps) wgrad_load_chunk(a1, b1, xp + (s + 8) * sx, zp + (s + 8) * sz, xo, zo, sx, sz, steps - s - 8);
         mma(a0, b0);
         if (s + 8 < steps) {
-            if (s + 16 < steps) wgrad_load_chunk(a0, b0, xp + (s + 16) * sx, zp + (s + 16) * sz, sx, sz, steps - s - 16, zv);
+            if (s + 16 < steps) wgrad_load_chunk(a0, b0, xp + (s + 16) * sx, zp + (s + 16) * sz, xo, zo, sx, sz, steps - s - 16);
             mma(a1, b1);
         }
     }
-    wgrad_finish(T, lds, acc, bs, tk, k0, n0, ntv);
+    wgrad_finish<2>(T, lds, acc, bs, tk, k0, n0, ntv, xv);
 }
-#define FQL_WGRAD_LDS_FLOATS (4 * 4 * 64 * 4 + 4 * 64)
-// precision = 2 weight gradient: same tile geometry, operand permutation, LDS reduction and summation order over waves.  The 8
-// batch rows a lane holds per chunk for X^T and for each dZ column are exactly one 16x16x32 operand each (the k order inside an
-// MFMA step is free as long as both operands share it), so a chunk is split in registers and multiplied with 3 x 4 bf16 MFMAs
-// instead of 32 fp32 ones; db stays an fp32 column sum.  Loads are branch-free (out-of-range steps / columns re-read a valid
-// address and are zeroed).
+// precision = 2 weight gradient: 16 x 64 tiles (FQL_WGRAD_KT_SPLIT: one input per lane - with two, as above, the bf16x3 update measured
+// 2.5 % slower although the serialised launches were not), same dZ permutation, LDS reduction and summation order over waves.  The 8
+// batch rows a lane holds per chunk for X^T and for each dZ column are exactly one 16x16x32 operand each (the k order inside an MFMA
+// step is free as long as both operands share it), so a chunk is split in registers and multiplied with 3 x 4 bf16 MFMAs instead of
+// 32 fp32 ones; db stays an fp32 column sum.  Loads are branch-free (out-of-range steps / columns re-read a valid address and are zeroed).
+#define FQL_WGRAD_KT_SPLIT 16
 __device__ __forceinline__ void wgrad_split_body(const WgradTask& T, int bid, float* lds) {
     const int local = bid - T.tile0;
     const int tk = sdiv(local, frcp(T.ntn)), tn = local - tk * T.ntn;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int c = lane & 15, q = lane >> 4;
-    const int k0 = tk * 16, n0 = tn * 64;
+    const int k0 = tk * FQL_WGRAD_KT_SPLIT, n0 = tn * 64;
     const int ntv = min(4, (T.N - n0) >> 4);  // valid 16-column tiles in this workgroup
     const bool zv = c < 4 * ntv;
     const int steps = T.M >> 4;               // MFMA steps (4 batch rows each) per wave
     const size_t sx = (size_t)4 * T.ldx, sz = (size_t)4 * T.ldz;
-    const float* __restrict__ xp = T.X + (size_t)(4 * wave * steps + q) * T.ldx + k0 + c;
-    const float* __restrict__ zp = T.dZ + (size_t)(4 * wave * steps + q) * T.ldz + n0 + min(4 * c, 16 * ntv - 4);
-    f32x4 acc[4];
+    const float* __restrict__ xp = T.X + (size_t)(4 * wave * steps) * T.ldx;    // uniform bases + 32-bit lane offsets, as in wgrad_body
+    const float* __restrict__ zp = T.dZ + (size_t)(4 * wave * steps) * T.ldz;
+    const unsigned xo = (unsigned)(q * T.ldx + k0 + c), zo = (unsigned)(q * T.ldz + n0 + min(4 * c, 16 * ntv - 4));
+    f32x4 acc[1][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 4; ++t) acc[0][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
     float a0[8], a1[8];
     f32x4 b0[8], b1[8];
@@ -1675,8 +1690,8 @@ __device__ __forceinline__ void wgrad_split_body(const WgradTask& T, int bid, fl
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int st = min(s0 + i, steps - 1);
-            a[i] = ldg(xp + st * sx);
-            b[i] = ldg4(zp + st * sz);
+            a[i] = ldg(xp + st * sx + xo);
+            b[i] = ldg4(zp + st * sz + zo);
         }
     };
     auto mma = [&](const float (&a)[8], const f32x4 (&b)[8], int s0) {
@@ -1698,9 +1713,9 @@ __device__ __forceinline__ void wgrad_split_body(const WgradTask& T, int bid, fl
                 bsplit2(b0v, b1v, h, l);
                 bh[i] = h; bl[i] = l;
             }
-            acc[t] = mfma_bf16(bh, al, acc[t]);
-            acc[t] = mfma_bf16(bl, ah, acc[t]);
-            acc[t] = mfma_bf16(bh, ah, acc[t]);
+            acc[0][t] = mfma_bf16(bh, al, acc[0][t]);
+            acc[0][t] = mfma_bf16(bl, ah, acc[0][t]);
+            acc[0][t] = mfma_bf16(bh, ah, acc[0][t]);
             __builtin_amdgcn_sched_barrier(0);   // keeps the compiler from hoisting every split in front of the MFMAs (spills)
         }
     };
@@ -1713,7 +1728,7 @@ __device__ __forceinline__ void wgrad_split_body(const WgradTask& T, int bid, fl
             mma(a1, b1, s + 8);
         }
     }
-    wgrad_finish(T, lds, acc, bs, tk, k0, n0, ntv);
+    wgrad_finish<1>(T, lds, acc, bs, tk, k0, n0, ntv, true);
 }
 __global__ __launch_bounds__(FQL_THREADS) void fql_wgrad_kernel(const WgradTask* __restrict__ tasks, int ntasks) {
     __shared__ __attribute__((aligned(16))) float lds_w[FQL_WGRAD_LDS_FLOATS];
