@@ -2104,7 +2104,11 @@ struct fql_engine {
             if (skip_lane >= 0 && pr.two_lanes && L.lane == skip_lane && L.type != OP_PREP) continue;
             hipStream_t s = par ? ls[L.lane] : s0;
             static const bool trace_l = getenv("FQL_TRACE") != nullptr;
-            if (trace_l) fprintf(stderr, "[fql] launch %d type %d lane %d waits %zu\n", (int)(&L - pr.launches.data()), (int)L.type, L.lane, L.waits.size());
+            if (trace_l) {
+                fprintf(stderr, "[fql] launch %d type %d lane %d grid %d waits %zu:", (int)(&L - pr.launches.data()), (int)L.type, L.lane, L.grid, L.waits.size());
+                for (int w : L.waits) fprintf(stderr, " %d(lane %d)", w, pr.launches[w].lane);
+                fprintf(stderr, "\n");
+            }
             if (par)
                 for (int w : L.waits) if (pr.launches[w].ev) HIP_CHECK(hipStreamWaitEvent(s, pr.launches[w].ev, 0));
             issue(L, s, (&pr == &prog_full) ? (int)(&L - pr.launches.data()) : -1);
@@ -2340,25 +2344,31 @@ struct fql_engine {
             place("enc", 1, true);
             emit_encoder_backward(pr, eb_c, 0, B, p_c1[0].dx0, p_c1[1].dx0, nets[NET_C0].in_p());
         }
-        // BC flow-matching pass (fql.py:52-59)
-        place("bcf", fill_lane, true);
-        emit_forward(pr, p_bc, with_grads);
-        place("bc", fill_lane, true);
-        {
-            Op op{};
-            op.type = OP_LOSS_BC;
-            op.lb = LossBcArgs{p_bc.out, vel, with_grads ? p_bc.dz.back() : nullptr, st, B, ad, ap, with_grads ? 1 : 0};
-            op.reads = {p_bc.out, vel};
-            op.writes = {I_BC};
-            if (with_grads) op.writes.push_back(p_bc.dz.back());
-            push(pr, op);
-        }
-        defer_wgrads = ((late_wgrad == 1 || late_wgrad == 3) && with_grads) ? &late_ops : nullptr;
-        if (with_grads) emit_backward(pr, p_bc, 0, B, true, visual);
-        if (with_grads && visual && !enc_align) {
-            place("enc", 1, true);
-            emit_encoder_backward(pr, eb_bc, 0, B, p_bc.dx0, nullptr, nets[NET_BC].in_p());
-        }
+        // BC flow-matching pass (fql.py:52-59).  FQL_BC_LATE=<lane> (three-lane programs): emitted BEHIND the Q-gradient path on that lane instead of
+        // on lane 2 in front of it - lane 1 idles from the end of the Q-gradient path to the end of the update while lane 2 carries the longest tail.
+        static const int bc_late_env = getenv("FQL_BC_LATE") ? atoi(getenv("FQL_BC_LATE")) : 0;
+        const int bc_late = (lanes3 && with_grads) ? bc_late_env : 0;
+        auto emit_bc = [&](int bc_lane) {
+            place("bcf", bc_lane, true);
+            emit_forward(pr, p_bc, with_grads);
+            place("bc", bc_lane, true);
+            {
+                Op op{};
+                op.type = OP_LOSS_BC;
+                op.lb = LossBcArgs{p_bc.out, vel, with_grads ? p_bc.dz.back() : nullptr, st, B, ad, ap, with_grads ? 1 : 0};
+                op.reads = {p_bc.out, vel};
+                op.writes = {I_BC};
+                if (with_grads) op.writes.push_back(p_bc.dz.back());
+                push(pr, op);
+            }
+            defer_wgrads = ((late_wgrad == 1 || late_wgrad == 3) && with_grads) ? &late_ops : nullptr;
+            if (with_grads) emit_backward(pr, p_bc, 0, B, true, visual);
+            if (with_grads && visual && !enc_align) {
+                place("enc", 1, true);
+                emit_encoder_backward(pr, eb_bc, 0, B, p_bc.dx0, nullptr, nets[NET_BC].in_p());
+            }
+        };
+        if (!bc_late) emit_bc(fill_lane);
         // Q term: critic(obs, clip(actor_actions)) with stored params, input-differentiable (fql.py:69-76)
         place("c2", 1, true);
         for (int e = 0; e < 2; ++e) emit_forward(pr, p_c2[e], with_grads);
@@ -2386,6 +2396,7 @@ struct fql_engine {
             emit_lane = w.lane;
             push(pr, w);
         }
+        if (bc_late) emit_bc(bc_late);
         // Euler chain through the BC flow (fql.py:155-171): flow_steps sequential forwards
         place("eu", 0, false);
         const int fs = cfg.flow_steps;
@@ -2421,6 +2432,10 @@ struct fql_engine {
                 op.reads.push_back(p_c2[0].dx0); op.reads.push_back(p_c2[1].dx0);
                 op.writes.push_back(p_os_bwd.dz.back());
             }
+            // FQL_TAIL_MERGE (see adam_for; default on): this kernel, first of lane 2's tail, also takes the edge to the end of lane 1's Q-gradient chain that
+            // the critic's Adam behind it needs (write after read of the critic's kernels) - both cross-lane waits of the tail on ONE launch
+            static const bool tail_merge = getenv("FQL_TAIL_MERGE") == nullptr || atoi(getenv("FQL_TAIL_MERGE")) != 0;   // default on
+            if (tail_merge && with_grads && !kgrad) { op.reads.push_back(p_c2[0].dx0); op.reads.push_back(p_c2[1].dx0); }
             const int keep = emit_lane;
             if (fuse_la && !split_build) emit_lane = fill_lane;
             if (euler_finish_fused) { la_op = op; la_lane = emit_lane; }   // pushed behind the head dgrad, which now WRITES the target
@@ -2510,6 +2525,10 @@ struct fql_engine {
             a.adam_c0 = mod_chunk0[m]; a.adam_n = mod_chunkn[m];
             a.reads = {st};
             a.writes = {d_partials + mod_chunk0[m] * 4};
+            // FQL_TAIL_MERGE (default on; =0 off): the critic's Adam, the first launch of lane 2's tail, also waits for the Euler target the actor-loss kernel behind it reads -
+            // one launch with two cross-lane edges instead of two launches with one each (every such edge costs the waiting lane ~10 us)
+            static const bool tail_merge = getenv("FQL_TAIL_MERGE") == nullptr || atoi(getenv("FQL_TAIL_MERGE")) != 0;   // default on
+            if (tail_merge && m == 2 && tgt) a.reads.push_back(tgt);
             if (visual) {
                 const int ei = m == 2 ? ENC_C : (m == 0 ? ENC_BC : ENC_OS);
                 for (const EncStack& st : encs[ei].stacks)
