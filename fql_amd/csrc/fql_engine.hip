@@ -185,6 +185,10 @@ struct Program {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     int64_t macs = 0;
+    // segment graphs (run_segments): maximal runs of one lane's launches without a cross-lane wait inside or a cross-lane reader in front of the end,
+    // each captured as its own LINEAR graph; first launch index, lane, member launches
+    struct Seg { int lane = 0; std::vector<int> idx; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+    std::vector<Seg> segs;
     // threaded eager issue (run_threaded): sequence number of the run whose event record of launch i has been enqueued
     std::unique_ptr<std::atomic<uint64_t>[]> rec;
     size_t rec_n = 0;
@@ -1414,6 +1418,8 @@ struct fql_engine {
         int maxlv = 0;
         for (const Op& op : pr.ops) maxlv = std::max(maxlv, op.level);
         pr.launches.clear();
+        for (Program::Seg& sg : pr.segs) { if (sg.exec) hipGraphExecDestroy(sg.exec); if (sg.graph) hipGraphDestroy(sg.graph); }
+        pr.segs.clear();
         pr.rec_n = 0;
         pr.two_lanes = false;
         for (bool& b : pr.lane_used) b = false;
@@ -2164,6 +2170,67 @@ struct fql_engine {
         if (trace_c) fprintf(stderr, "[fql] instantiated\n");
     }
 
+    // FQL_SEG_GRAPHS=1: the update as a handful of LINEAR graphs, one per stretch of a lane between two cross-lane dependencies, launched on the lane
+    // streams with real events between them.  hipGraphLaunch of the whole three-lane graph costs the host ~300 us (3.6 us per node: a multi-queue graph is
+    // walked node by node) - as much as the update takes on the device; a linear graph of the same nodes costs ~0.5 us per node (measured with
+    // DEBUG_HIP_FORCE_GRAPH_QUEUES=1: 37 us for all 83).
+    void build_segments(Program& pr) {
+        int cur[FQL_LANES];
+        for (int l = 0; l < FQL_LANES; ++l) cur[l] = -1;
+        for (int li = 0; li < (int)pr.launches.size(); ++li) {
+            const Launch& L = pr.launches[li];
+            if (cur[L.lane] < 0 || !L.waits.empty()) {
+                pr.segs.emplace_back();
+                pr.segs.back().lane = L.lane;
+                cur[L.lane] = (int)pr.segs.size() - 1;
+            }
+            pr.segs[cur[L.lane]].idx.push_back(li);
+            if (L.record_after) cur[L.lane] = -1;
+        }
+        // (segments were opened in launch order = a topological order: a segment's only waits are those of its first launch)
+        HIP_CHECK(hipStreamSynchronize(stream));
+        for (Program::Seg& sg : pr.segs) {
+            HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            try {
+                for (int li : sg.idx) issue(pr.launches[li], stream, (&pr == &prog_full) ? li : -1);
+            } catch (...) {
+                hipGraph_t g = nullptr;
+                hipStreamEndCapture(stream, &g);
+                if (g) hipGraphDestroy(g);
+                throw;
+            }
+            HIP_CHECK(hipStreamEndCapture(stream, &sg.graph));
+            HIP_CHECK(hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0));
+        }
+        if (getenv("FQL_TRACE")) fprintf(stderr, "[fql] %zu segment graphs for %zu launches\n", pr.segs.size(), pr.launches.size());
+    }
+    void run_segments(Program& pr, hipStream_t s0) {
+        if (pr.segs.empty()) build_segments(pr);
+        hipStream_t ls[FQL_LANES] = {s0, stream2, stream3, stream4};
+        if (pr.two_lanes) {
+            if (!pr.ev_fork) HIP_CHECK(hipEventCreateWithFlags(&pr.ev_fork, hipEventDisableTiming));
+            HIP_CHECK(hipEventRecord(pr.ev_fork, s0));
+            for (int l = 1; l < FQL_LANES; ++l) if (pr.lane_used[l]) HIP_CHECK(hipStreamWaitEvent(ls[l], pr.ev_fork, 0));
+        }
+        for (Program::Seg& sg : pr.segs) {
+            hipStream_t s = ls[sg.lane];
+            for (int w : pr.launches[sg.idx.front()].waits) if (pr.launches[w].ev) HIP_CHECK(hipStreamWaitEvent(s, pr.launches[w].ev, 0));
+            HIP_CHECK(hipGraphLaunch(sg.exec, s));
+            Launch& last = pr.launches[sg.idx.back()];
+            if (last.record_after) {
+                if (!last.ev) HIP_CHECK(hipEventCreateWithFlags(&last.ev, hipEventDisableTiming));
+                HIP_CHECK(hipEventRecord(last.ev, s));
+            }
+        }
+        if (pr.two_lanes)
+            for (int l = 1; l < FQL_LANES; ++l) {
+                if (!pr.lane_used[l]) continue;
+                if (!pr.ev_join[l]) HIP_CHECK(hipEventCreateWithFlags(&pr.ev_join[l], hipEventDisableTiming));
+                HIP_CHECK(hipEventRecord(pr.ev_join[l], ls[l]));
+                HIP_CHECK(hipStreamWaitEvent(s0, pr.ev_join[l], 0));
+            }
+    }
+
     // one graph per segment: seg 0 = lane-0 launches up to the last one lane 1 waits on, seg 1 = lane 1, seg 2 = lane 0 up to
     // its first wait on lane 1, seg 3 = the rest of lane 0.  Returns false if the program does not have that shape.
     bool capture_split(Program& pr) {
@@ -2231,6 +2298,7 @@ struct fql_engine {
     void free_program(Program& pr) {
         if (pr.exec) hipGraphExecDestroy(pr.exec);
         if (pr.graph) hipGraphDestroy(pr.graph);
+        for (Program::Seg& sg : pr.segs) { if (sg.exec) hipGraphExecDestroy(sg.exec); if (sg.graph) hipGraphDestroy(sg.graph); }
         for (Launch& L : pr.launches) if (L.ev) hipEventDestroy(L.ev);
         if (pr.ev_fork) hipEventDestroy(pr.ev_fork);
         for (hipEvent_t e : pr.ev_join) if (e) hipEventDestroy(e);
@@ -3318,7 +3386,9 @@ static void run_program(fql_handle h, Program& pr, hipStream_t s) {
     static const bool eager_lanes = getenv("FQL_NO_GRAPH") && atoi(getenv("FQL_NO_GRAPH")) == 2;   // eager launches on the lane streams
     static const bool split_default = getenv("FQL_SPLIT_DEFAULT") != nullptr;  // experiment: host-launched lane graphs
     static const bool threaded = getenv("FQL_NO_GRAPH") && atoi(getenv("FQL_NO_GRAPH")) == 3;      // ... one host thread per lane
-    if (threaded) h->run_threaded(pr, s);
+    static const bool seg_graphs = getenv("FQL_SEG_GRAPHS") != nullptr && atoi(getenv("FQL_SEG_GRAPHS")) != 0;   // linear graphs per lane stretch, real events between
+    if (seg_graphs && !no_graph && pr.two_lanes) h->run_segments(pr, s);
+    else if (threaded) h->run_threaded(pr, s);
     else if (eager_lanes) h->run_launches(pr, s, true);
     else if (no_graph) h->run_launches(pr, s);
     else if (split_default && (&pr == &h->prog_fwdbwd) && h->split_ok && s != h->stream2) h->launch_split(s, h->stream2);
