@@ -150,6 +150,7 @@ struct Op {
     int wprep_n = 0;
     int cw_grid = 0;
     int adam_c0 = 0, adam_n = -1;  // chunk range of an Adam op (-1: all chunks)
+    int adam_c1 = 0, adam_n1 = 0;  // second chunk range of the same launch (two modules merged), adam_n1 = 0: none
     int fin_mode = 0;
     int level = 0;
     int lane = 0;            // 0 = critical lane (Euler chain, one-step backward), 1 = side lane
@@ -1954,8 +1955,8 @@ struct fql_engine {
                 break;
             case OP_ADAM: {
                 AdamArgs a{P, G, Mu, Nu, P + n_train, d_chunks, d_state, d_partials, L.op.adam_c0, (int)critic_size, cfg.lr, cfg.tau, tl,
-                           use_pec ? (const unsigned*)(pec_epoch + pec_teams) : nullptr};
-                FQL_LAUNCH(fql_adam_kernel, dim3(L.op.adam_n < 0 ? n_chunks : L.op.adam_n), dim3(FQL_THREADS), 0, s, a);
+                           use_pec ? (const unsigned*)(pec_epoch + pec_teams) : nullptr, L.op.adam_n1 > 0 ? L.op.adam_n : -1, L.op.adam_c1};
+                FQL_LAUNCH(fql_adam_kernel, dim3(L.op.adam_n < 0 ? n_chunks : L.op.adam_n + L.op.adam_n1), dim3(FQL_THREADS), 0, s, a);
                 break;
             }
             case OP_FINALIZE:
@@ -2586,18 +2587,21 @@ struct fql_engine {
     }
 
     // Adam (+ Polyak for the critic) of one module (0 BC flow, 1 one-step actor, 2 critic) as its own launch on `lane`
-    void adam_for(Program& pr, int m, std::initializer_list<int> net_ids, int lane) {
+    // m2 >= 0: a second module (its nets in net_ids as well) rides in the same launch
+    void adam_for(Program& pr, int m, std::initializer_list<int> net_ids, int lane, int m2 = -1) {
         DevState* st = d_state;
             Op a{};
             a.type = OP_ADAM;
             a.adam_c0 = mod_chunk0[m]; a.adam_n = mod_chunkn[m];
             a.reads = {st};
             a.writes = {d_partials + mod_chunk0[m] * 4};
+            if (m2 >= 0) { a.adam_c1 = mod_chunk0[m2]; a.adam_n1 = mod_chunkn[m2]; a.writes.push_back(d_partials + mod_chunk0[m2] * 4); }
             // FQL_TAIL_MERGE (default on; =0 off): the critic's Adam, the first launch of lane 2's tail, also waits for the Euler target the actor-loss kernel behind it reads -
             // one launch with two cross-lane edges instead of two launches with one each (every such edge costs the waiting lane ~10 us)
             static const bool tail_merge = getenv("FQL_TAIL_MERGE") == nullptr || atoi(getenv("FQL_TAIL_MERGE")) != 0;   // default on
             if (tail_merge && m == 2 && tgt) a.reads.push_back(tgt);
-            if (visual) {
+            for (int mm : {m, m2}) if (visual && mm >= 0) {
+                const int m = mm;
                 const int ei = m == 2 ? ENC_C : (m == 0 ? ENC_BC : ENC_OS);
                 for (const EncStack& st : encs[ei].stacks)
                     for (const ConvL& c : st.conv) {
@@ -2671,8 +2675,14 @@ struct fql_engine {
     void build_full_program(Program& pr) {
         build_step_program(pr, true);
         DevState* st = d_state;
-        adam_for(pr, 2, {NET_C0, NET_C1}, fill_lane_full);
-        adam_for(pr, 0, {NET_BC}, fill_lane_full);
+        // the critic's and the BC flow's Adam as ONE launch (FQL_ADAM_MERGE=0: two): both sit at the end of the same lane behind the same
+        // dependencies, and every graph node costs the host 3-4 us
+        static const bool adam_merge = getenv("FQL_ADAM_MERGE") == nullptr || atoi(getenv("FQL_ADAM_MERGE")) != 0;
+        if (adam_merge) adam_for(pr, 2, {NET_C0, NET_C1, NET_BC}, fill_lane_full, 0);
+        else {
+            adam_for(pr, 2, {NET_C0, NET_C1}, fill_lane_full);
+            adam_for(pr, 0, {NET_BC}, fill_lane_full);
+        }
         emit_wfrag(pr);   // lane 1, behind the BC flow's Adam: the next update's chain reads the copies
         adam_for(pr, 1, {NET_OS}, 0);
         Op f{};

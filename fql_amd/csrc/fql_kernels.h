@@ -2162,6 +2162,7 @@ struct AdamArgs {
     float lr, tau;
     int tl;
     const unsigned* err;   // persistent Euler chain only: its time-out word; set => the update's targets are invalid, leave the parameters alone
+    int n0, chunk1;        // two modules in one launch: workgroups [0, n0) take chunks chunk0 + b, the rest chunk1 + (b - n0); n0 < 0: one range
 };
 __device__ __forceinline__ int f2ord(float f) {
     const int i = __float_as_int(f);
@@ -2173,7 +2174,7 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_adam_kernel(AdamArgs A) {
     __shared__ float sh[4];
     tl_enter(A.tl);
     if (A.err && __hip_atomic_load(A.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // (null unless FQL_PEC=1)
-    const int cidx = (int)blockIdx.x + A.chunk0;
+    const int cidx = (A.n0 < 0 || (int)blockIdx.x < A.n0) ? (int)blockIdx.x + A.chunk0 : (int)blockIdx.x - A.n0 + A.chunk1;
     const AdamChunk ch = A.chunks[cidx];  // <= 4096 elements, offset and length multiples of 4
     // optax bias correction with count = adam_count + 1 (the counters advance in the finalize kernel afterwards)
     const float c1 = (float)(1.0 - A.st->b1pow * 0.9), c2 = (float)(1.0 - A.st->b2pow * 0.999);
