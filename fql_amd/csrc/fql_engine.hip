@@ -2103,7 +2103,26 @@ struct fql_engine {
             hipLaunchKernelGGL(fql_blocker_kernel, dim3(nb), dim3(FQL_THREADS), lds, ls[3], (unsigned long long)blocker_us * 100ull);
             pr.lane_used[3] = true;
         }
-        for (Launch& L : pr.launches) {
+        // FQL_CAPTURE_GROUPED=1 (experiment): issue - and so capture - the launches stretch by stretch (a lane's launches between two cross-lane
+        // dependencies back to back; stretches in the order of their first launch, which is still a topological order) instead of level by level
+        static const bool grouped = getenv("FQL_CAPTURE_GROUPED") != nullptr && atoi(getenv("FQL_CAPTURE_GROUPED")) != 0;
+        std::vector<int> order;
+        if (grouped && par) {
+            std::vector<std::vector<int>> st;
+            int cur[FQL_LANES];
+            for (int l = 0; l < FQL_LANES; ++l) cur[l] = -1;
+            for (int li = 0; li < (int)pr.launches.size(); ++li) {
+                const Launch& L = pr.launches[li];
+                if (cur[L.lane] < 0 || !L.waits.empty()) { st.emplace_back(); cur[L.lane] = (int)st.size() - 1; }
+                st[cur[L.lane]].push_back(li);
+                if (L.record_after) cur[L.lane] = -1;
+            }
+            for (const auto& v : st) for (int li : v) order.push_back(li);
+        } else {
+            for (int li = 0; li < (int)pr.launches.size(); ++li) order.push_back(li);
+        }
+        for (int oi : order) {
+            Launch& L = pr.launches[oi];
             static const int max_launch = getenv("FQL_MAX_LAUNCH") ? atoi(getenv("FQL_MAX_LAUNCH")) : -1;   // capture-crash bisection
             if (max_launch >= 0 && (int)(&L - pr.launches.data()) >= max_launch) continue;
             if (only_lane >= 0 && pr.two_lanes && L.lane != only_lane) continue;
