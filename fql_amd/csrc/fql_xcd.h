@@ -1,0 +1,682 @@
+// fql_xcd.h -- the XCD-resident update kernel (round 3).
+//
+// One persistent launch runs every forward pass and every input-gradient pass of one FQL update (agents/fql.py:22-92, 155-171;
+// utils/networks.py:34-61): the batch is cut into 8 row blocks, one per XCD, and the 32 workgroups (one per CU) that the dispatcher
+// places on an XCD take that block through every layer.  A layer is split over the 32 members by output columns (16 each at H = 512), so
+// a member needs the whole [rows x K] activation panel of its block: it is exchanged through THAT XCD's L2 only (plain stores, which
+// stay in the L2; loads with sc1, which bypass the reader's L1), behind one arrival counter per XCD.  There is no kernel boundary
+// between dependent layers (1.6 us + a cold L2 each, 82 of them per update in the launch-per-level program this replaces), no cross-XCD
+// traffic inside the launch, and the Euler chain's hidden kernels stay in LDS for all flow_steps.  Rows never meet across XCDs inside the
+// launch: every loss of the path is a mean over independent rows (agents/fql.py:37,59,66,73); what does reduce over the batch - weight
+// gradients, LayerNorm scale / bias gradients, the info scalars - is left to the launches behind this one (per-XCD partials for the
+// scalars).  experiments/xcd_phase.hip is the microbenchmark the design was priced with (2.7 us per dependent 512 x 512 layer).
+//
+// Groups are formed from HW_REG_XCC_ID - the XCD a workgroup really runs on - and members by a per-XCD ticket, so the result never
+// depends on which workgroup landed where; what the kernel does need is 32 resident workgroups per XCD (a 256-workgroup grid at one per
+// CU).  A group that is short of members times out in its first wait, sets the error word and drains (every spin is bounded); the
+// optimizer launch behind it then leaves the parameters alone and the host reports the failure when the infos are read.
+//
+// Layout.  Inside the launch every [rows, H] tensor (activations, GELU', gradients) lives TILE-MAJOR: 16 x 16 tiles, a tile the 1 KB
+// [column quad q][row r][4 columns] - the order the MFMA operand of the next layer wants, so a wave loads or stores a tile as one fully
+// coalesced dwordx4 instruction (row-major buffers cost four times the L2 requests: the 16 lanes of a quarter wave sit in 16 different
+// rows).  What the launches BEHIND this one read (weight gradients, LayerNorm scale / bias gradients: X, dZ, dY, g, row statistics) is
+// also stored row-major, one extra store per epilogue.  16-wide tensors (heads, actions) are row-major only: a 16 x 16 tile of a
+// 16-wide matrix is contiguous either way.
+//
+// The product MFMA is v_mfma_f32_16x16x4_f32 in its "transposed" use: weights are the first operand, activations the second, so a
+// lane (r, q) of the accumulator holds out[row r][columns 4 q .. 4 q + 3] - exactly the 16 bytes the NEXT layer's lane loads as its
+// operand, and one dwordx4 store per lane in the epilogue.
+#pragma once
+
+#define XCD_NMEM 32
+#define XCD_NGRP 8
+#define XCD_MAXROWS 128        // rows per XCD (batch <= 1024)
+
+enum : int { XK_FWD = 0, XK_HEAD, XK_DGRAD, XK_SEED_DGRAD, XK_LNBWD, XK_CHAIN_L0, XK_CHAIN_MID, XK_CHAIN_LAST, XK_METRICS };
+enum : int {
+    XF_GELU = 1 << 0,        // GELU-tanh epilogue (utils/networks.py:46,56)
+    XF_SAVEZ = 1 << 1,       // also store GELU'(z) (backward multiplies by it: no transcendental there)
+    XF_BIAS = 1 << 2,
+    XF_LN = 1 << 3,          // LayerNorm the A panel first (utils/networks.py:58; flax fast variance, eps 1e-6)
+    XF_LN_STORE = 1 << 4,    // ... and store LN(A) (this member's columns) and the row statistics for the backward pass
+    XF_ZMUL = 1 << 5,        // dgrad epilogue: C = acc * GELU'(z) of the layer below
+    XF_OS_SCATTER = 1 << 6,  // one-step head on [next_obs ; obs ; obs] rows: clip(out) into the critic inputs (agents/fql.py:26,69)
+    XF_SEED_ACTOR = 1 << 7,  // XK_SEED_DGRAD: A = d(actor loss)/d(one-step actions) (agents/fql.py:66-79), after folding the last Euler step
+    XF_SYN = 1 << 8,         // XK_LNBWD: dY = dq (x) w (scalar head, rank 1)
+    XF_SEED_CRITIC = 1 << 9, // XK_LNBWD + XF_SYN: dq = (q - y) / B computed here (agents/fql.py:28-37) and stored for the head's weight gradient
+    XF_A_TILE = 1 << 10,     // A is tile-major [rows / 16][K / 16][4][16][4] (else row-major with lda)
+};
+
+struct XOp {
+    int kind, flags;
+    const float* A;      // [rows, lda] activations (XK_LNBWD: dY)
+    const float* W;      // kernel [in][out] row-major as flax stores it (forward: in = K, dgrad: in = N)
+    const float* bias;
+    float* C;            // [rows, ldc] row-major copy of the output (null: none)
+    float* Ct;           // tile-major copy of the output (null: none)
+    float* Zout;         // XF_SAVEZ: GELU'(z), tile-major
+    const float* Zmul;   // XF_ZMUL / XK_LNBWD: stored GELU'(z), tile-major
+    const float *ln_g, *ln_b;
+    float* ln_xout;      // XF_LN_STORE
+    float* ln_stats;     // XF_LN_STORE: [rows, 2] mean, rstd (XK_LNBWD: read)
+    int lda, ldw, ldc, K, N;
+    int nblk, blk_stride;   // stacked row blocks (one-step actor: 3 blocks of B rows)
+    int member0;            // column tile t (or LNBWD row) is taken by member (t + member0) % 32
+    int step;               // chain ops: Euler step
+    // kind-specific operands
+    const float *p0, *p1, *p2, *p3, *p4, *p5;
+    float *o0, *o1;
+    int i0, i1;
+    float f0, f1;
+};
+
+struct XPhase { int first, count; };
+
+struct XcdArgs {
+    const XOp* ops;
+    const XPhase* phases;
+    int nphase;
+    int B, R, RT;            // batch, rows per XCD, 16-row tiles per XCD
+    unsigned* sync;          // [0, 8): arrival counters (32 words apart), [8, 16): tickets, word 16 * 32: error flag; zeroed by the prep launch
+    float* xpart;            // [8][16] per-XCD partial sums of the info scalars
+    // Euler chain (agents/fql.py:155-171)
+    const float* chain_w[7]; // hidden kernels 1 .. nh - 1 of the BC flow, [H][H]
+    int chain_nl;            // how many of them (LDS resident: chain_nl * H * 64 bytes)
+    int H;                   // hidden width of the BC flow
+    const float* w0;         // its first kernel [in_p][H]: rows od .. od + 15 are the rank-16 update of layer 0
+    const float* w4;         // its head kernel [H][ap]
+    const float* b4;         // head bias
+    const float* x_eu;       // [B, in_p] (obs | z | 0): initial actions
+    float* vp;               // head partials [32][B][16]
+    float* tgt;              // [B, ap] clip(Euler result) (written by member 0 for the metrics / debugging)
+    int od, ad, ap, in_p, fs;
+    int lds_floats;
+    unsigned long long* stamps2;  // diagnostics build: [256][16] stamps inside the ops of phase `stamp_phase`
+    int stamp_phase;
+    unsigned long long* stamps;   // diagnostics build (-DFQL_XSTAMPS): [256 workgroups][phases][4] s_memrealtime ticks (10 ns): wait over, ops done, drained, arrived
+};
+
+__device__ __forceinline__ f32x4 ldx4(const float* base, unsigned off) {   // 16-byte load that bypasses this CU's L1 (sc1): data another CU of the XCD wrote
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7FFFFFFF, 0x00020000);
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off * 4u), 0, 16));
+}
+__device__ __forceinline__ float ldx1(const float* base, unsigned off) {
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7FFFFFFF, 0x00020000);
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(off * 4u), 0, 16));
+}
+
+struct XCtx {
+    int g, member, wave, lane, r, q;
+    int R, RT;
+    f32x4* red;     // [4 waves][4 tiles][64] cross-wave reduction
+    float* stat;    // [4 waves][4 tiles][16 rows][2]
+    float* alds;    // [R][16] current Euler actions (+ t column)
+    const f32x4* wlds;
+    unsigned long long* st2;
+};
+#ifdef FQL_XSTAMPS
+#define XST(c, k) do { if ((c).st2 && threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); (c).st2[k] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define XST(c, k) do {} while (0)
+#endif
+
+// row base (global row of the [rows, ld] buffers) of tile ti of an op
+__device__ __forceinline__ int xrow(const XCtx& c, const XOp& o, int ti) {
+    const int blk = ti / c.RT, t = ti - blk * c.RT;
+    return blk * o.blk_stride + c.g * c.R + 16 * t;
+}
+
+// ---- the dense core: out[rows of this XCD][16 columns of this member] ------------------------------------------------------------
+// K is split over the four waves (wave w takes the 16-deep slices j = w, w + 4, ...: NJ of them, compile time); NT row tiles per pass
+// (compile time: a conditional MFMA makes the compiler shuttle accumulators between register files around every product) share a
+// weight fragment; partial accumulators meet in LDS and wave u finishes row tile u.  Slices beyond K load zeros.
+template <int NT, int NJ, class RowOf, class ALoad, class Pro, class WLoad, class Epi>
+__device__ __forceinline__ void xdense_nt(const XCtx& c, int K, int N, int ntl, int mrel, RowOf rowof, ALoad aload, Pro pro, WLoad wload, Epi epi) {
+    const int J = K >> 4, ntn = N >> 4;
+    for (int ct = mrel; ct < ntn; ct += XCD_NMEM) {
+        const int n0 = ct << 4;
+        XST(c, 1);
+        f32x4 wv[NJ];
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int j = c.wave + 4 * jj;
+            wv[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (j < J) wv[jj] = wload(n0, j);
+        }
+        for (int t0 = 0; t0 < ntl; t0 += NT) {
+            int rb[NT];   // row bases of the tiles of this pass: wave-uniform
+#pragma unroll
+            for (int u = 0; u < NT; ++u) rb[u] = rowof(t0 + u);
+            f32x4 av[NT][NJ];
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                const int j = c.wave + 4 * jj;
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    av[u][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (j < J) av[u][jj] = aload(rb[u], j);
+                }
+            }
+            XST(c, 2);
+            pro(av, rb, J, ct);
+            XST(c, 3);
+            f32x4 acc[NT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[jj][t], av[u][jj][t], acc[u], 0, 0, 0);
+            XST(c, 4);
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < NT; ++u) c.red[(c.wave * 4 + u) * 64 + c.lane] = acc[u];
+            __syncthreads();
+            XST(c, 5);
+            if (c.wave < NT) {
+                f32x4 s = c.red[(0 * 4 + c.wave) * 64 + c.lane];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) s += c.red[(w * 4 + c.wave) * 64 + c.lane];
+                int rbw = rb[0];
+#pragma unroll
+                for (int u = 1; u < NT; ++u) if (c.wave == u) rbw = rb[u];
+                epi(rbw, n0, s);
+            }
+            XST(c, 6);
+        }
+    }
+}
+template <int NJ, class RowOf, class ALoad, class Pro, class WLoad, class Epi>
+__device__ __forceinline__ void xdense(const XCtx& c, int K, int N, int ntl, int mrel, RowOf rowof, ALoad aload, Pro pro, WLoad wload, Epi epi) {
+    if (ntl & 1) xdense_nt<1, NJ>(c, K, N, ntl, mrel, rowof, aload, pro, wload, epi);
+    else xdense_nt<2, NJ>(c, K, N, ntl, mrel, rowof, aload, pro, wload, epi);
+}
+
+struct XNoPro {
+    template <int NT, int NJ>
+    __device__ __forceinline__ void operator()(f32x4 (&)[NT][NJ], const int (&)[NT], int, int) const {}
+};
+
+// LayerNorm of the A panel in registers (utils/networks.py:58): every member needs every row's statistics and has the whole row
+// (a K-quarter per wave), so each computes them itself - no partial-sum buffers, no extra phase.
+struct XLnPro {
+    const XCtx& c;
+    const XOp& o;
+    template <int NT, int NJ>
+    __device__ __forceinline__ void operator()(f32x4 (&av)[NT][NJ], const int (&rb)[NT], int J, int ct) const {
+        float s1[NT], s2[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            s1[u] = s2[u] = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { const float v = av[u][jj][t]; s1[u] += v; s2[u] += v * v; }   // (slices beyond J and tiles beyond nt are zeros)
+            s1[u] += __shfl_xor(s1[u], 16); s1[u] += __shfl_xor(s1[u], 32);
+            s2[u] += __shfl_xor(s2[u], 16); s2[u] += __shfl_xor(s2[u], 32);
+        }
+        __syncthreads();   // (the statistics slots of the previous pass have been read)
+        if (c.q == 0) {
+#pragma unroll
+            for (int u = 0; u < NT; ++u) { c.stat[((c.wave * 4 + u) * 16 + c.r) * 2] = s1[u]; c.stat[((c.wave * 4 + u) * 16 + c.r) * 2 + 1] = s2[u]; }
+        }
+        __syncthreads();
+        const float inv = 1.0f / (float)o.K;
+        const bool store_all = (o.N >> 4) == 1;   // a single-tile op (the scalar / action heads): its one member stores the whole normalised panel
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { a1 += c.stat[((w * 4 + u) * 16 + c.r) * 2]; a2 += c.stat[((w * 4 + u) * 16 + c.r) * 2 + 1]; }
+            const float mean = a1 * inv;
+            const float var = fmaxf(a2 * inv - mean * mean, 0.0f);
+            const float rstd = 1.0f / sqrtf(var + 1e-6f);
+            const int row = rb[u] + c.r;
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                const int j = c.wave + 4 * jj;
+                if (j < J) {
+                    const f32x4 gm = ldg4(o.ln_g + 16 * j + 4 * c.q), bt = ldg4(o.ln_b + 16 * j + 4 * c.q);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) av[u][jj][t] = (av[u][jj][t] - mean) * rstd * gm[t] + bt[t];
+                    if ((o.flags & XF_LN_STORE) && (j == ct || store_all)) stg4(o.ln_xout + (size_t)row * o.lda + 16 * j + 4 * c.q, av[u][jj]);
+                }
+            }
+            if ((o.flags & XF_LN_STORE) && ct == 0 && c.wave == 0 && c.q == 0) {
+                stg(o.ln_stats + 2 * (size_t)row, mean);
+                stg(o.ln_stats + 2 * (size_t)row + 1, rstd);
+            }
+        }
+    }
+};
+
+// ---- Euler chain helpers -----------------------------------------------------------------------------------------------------------
+// a_s = a_{s-1} + (sum of the 32 members' head partials of step s - 1 + head bias) / flow_steps, t column := s / flow_steps
+// (agents/fql.py:166-169); every member folds for itself (the partials are [32][rows][16] floats, of which act_dim columns are live) and
+// keeps the actions of its XCD's rows in LDS.  s = 0: the noise z.
+__device__ __forceinline__ void xchain_fold(const XCtx& c, const XcdArgs& a, int s) {
+    const int nq = (a.ad + 3) >> 2;   // live column quads of a partial row
+    if (s == 0) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < c.R * 16; e += 256) {
+            const int row = e >> 4, col = e & 15;
+            c.alds[e] = col < a.ad ? ldg(a.x_eu + (size_t)(c.g * c.R + row) * a.in_p + a.od + col) : 0.f;
+        }
+        __syncthreads();
+        return;
+    }
+    const float inv = 1.0f / (float)a.fs;
+    for (int t0 = 0; t0 < c.RT; t0 += 4) {
+        const int nt = min(4, c.RT - t0);
+        f32x4 pa[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            pa[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (u < nt && c.q < nq) {
+#pragma unroll
+                for (int mm = 0; mm < 8; ++mm) {
+                    const int m = c.wave + 4 * mm;
+                    pa[u] += ldx4(a.vp, (unsigned)(((size_t)m * a.B + c.g * c.R + 16 * (t0 + u) + c.r) * 16 + 4 * c.q));
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u < nt) c.red[(c.wave * 4 + u) * 64 + c.lane] = pa[u];
+        __syncthreads();
+        if (c.wave < nt) {
+            f32x4 v = c.red[(0 * 4 + c.wave) * 64 + c.lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) v += c.red[(w * 4 + c.wave) * 64 + c.lane];
+            float* ar = c.alds + (16 * (t0 + c.wave) + c.r) * 16 + 4 * c.q;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int col = 4 * c.q + t;
+                if (col < a.ad) ar[t] = ar[t] + (v[t] + ldg(a.b4 + col)) * inv;
+                else if (col == a.ad) ar[t] = (float)s * inv;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// ---- one op of a phase ---------------------------------------------------------------------------------------------------------------
+// offset (floats) of lane (r, q)'s 16 bytes of tile (row base rb, column tile ct) of a tile-major [rows, 16 ntn] tensor
+__device__ __forceinline__ unsigned xtoff(const XCtx& c, int rb, int ct, int ntn) { return (unsigned)((((rb >> 4) * ntn + ct) << 8) + (c.lane << 2)); }
+
+__device__ __forceinline__ void xrun(const XCtx& c, const XcdArgs& a, const XOp* op, const float (&w4f)[4]) {
+    // the op table is constant for the launch: read through the constant address space, so every field is a scalar load into SGPRs
+    // (as generic global loads they come back in VGPRs, and every buffer load whose descriptor is built from one gets a waterfall loop)
+    XOp o;
+    {
+        const __attribute__((address_space(4))) unsigned* src = (const __attribute__((address_space(4))) unsigned*)op;
+        unsigned* dst = reinterpret_cast<unsigned*>(&o);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(XOp) / 4); ++i) dst[i] = src[i];
+    }
+    const int mrel = (c.member - o.member0) & (XCD_NMEM - 1);
+    const int ntl = o.nblk * c.RT;
+    XST(c, 0);
+    auto rowof = [&](int ti) { return xrow(c, o, ti); };
+    const int JA = o.K >> 4, NTN = o.N >> 4;
+    auto aload = [&](int rb, int j) {
+        if (o.flags & XF_A_TILE) return ldx4(o.A, xtoff(c, rb, j, JA));
+        return ldx4(o.A, (unsigned)((size_t)(rb + c.r) * o.lda + 16 * j + 4 * c.q));
+    };
+    auto wfwd = [&](int n0, int j) {   // forward: lane (r, q) needs W[16 j + 4 q + t][n0 + r], t = 0..3
+        f32x4 v;
+        const float* p = o.W + (size_t)(16 * j + 4 * c.q) * o.ldw + n0 + c.r;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = ldg(p + (size_t)t * o.ldw);
+        return v;
+    };
+    // both copies of an output tile: tile-major for the next op of this launch, row-major for the launches behind it
+    auto store_out = [&](int rb, int n0, const f32x4& v) {
+        if (o.Ct) stg4(o.Ct + xtoff(c, rb, n0 >> 4, NTN), v);
+        if (o.C) stg4(o.C + (size_t)(rb + c.r) * o.ldc + n0 + 4 * c.q, v);
+    };
+    switch (o.kind) {
+        case XK_FWD:
+        case XK_HEAD: {
+            auto epi = [&](int rb, int n0, f32x4 v) {
+                const int row = rb + c.r;
+                if (o.flags & XF_BIAS) v += ldg4(o.bias + n0 + 4 * c.q);
+                if (o.flags & XF_GELU) {
+                    f32x4 g, dg;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { float gg, dd; gelu_both(v[t], gg, dd); g[t] = gg; dg[t] = dd; }
+                    store_out(rb, n0, g);
+                    if (o.flags & XF_SAVEZ) stg4(o.Zout + xtoff(c, rb, n0 >> 4, NTN), dg);
+                } else {
+                    store_out(rb, n0, v);
+                }
+                if (o.flags & XF_OS_SCATTER) {   // o0 = X_ct, o1 = X_c2; i0 = their ld, i1 = obs_dim
+                    const int blk = rb >= 2 * o.blk_stride ? 2 : (rb >= o.blk_stride ? 1 : 0);
+                    float* dst = blk == 0 ? o.o0 : (blk == 1 ? o.o1 : nullptr);
+                    if (dst) {
+                        const int brow = row - blk * o.blk_stride;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (n0 + 4 * c.q + t < a.ad) stg(dst + (size_t)brow * o.i0 + o.i1 + n0 + 4 * c.q + t, clip1(v[t]));
+                    }
+                }
+            };
+            if (o.flags & XF_LN) xdense<8>(c, o.K, o.N, ntl, mrel, rowof, aload, XLnPro{c, o}, wfwd, epi);
+            else if (o.K <= 64) xdense<1>(c, o.K, o.N, ntl, mrel, rowof, aload, XNoPro{}, wfwd, epi);
+            else xdense<8>(c, o.K, o.N, ntl, mrel, rowof, aload, XNoPro{}, wfwd, epi);
+            break;
+        }
+        case XK_DGRAD: {   // C = A W^T: out column n <-> input neuron, lane (r, q) needs W[n0 + r][16 j + 4 q ..]: one dwordx4
+            auto wbwd = [&](int n0, int j) { return ldg4(o.W + (size_t)(n0 + c.r) * o.ldw + 16 * j + 4 * c.q); };
+            auto epi = [&](int rb, int n0, f32x4 v) {
+                if (o.flags & XF_ZMUL) v *= ldx4(o.Zmul, xtoff(c, rb, n0 >> 4, NTN));
+                store_out(rb, n0, v);
+            };
+            xdense<8>(c, o.K, o.N, ntl, mrel, rowof, aload, XNoPro{}, wbwd, epi);
+            break;
+        }
+        case XK_SEED_DGRAD: {
+            // head dgrad of an actor with the loss gradient built in place of the A load (K = 16):
+            //   BC flow (agents/fql.py:58-59):  d = 2 (pred - vel) / (B ad)                      p0 = pred, p1 = vel, f0 = 2 / (B ad)
+            //   one-step actor (:66-79):        d = alpha 2 (mu - tgt) / (B ad) + [|mu| < 1] (dQa + dQb)
+            //                                   p0 = mu rows (raw one-step output of the (obs, z) block), p2 / p3 = critic input gradients [B, i0],
+            //                                   i1 = obs_dim, f0 = alpha 2 / (B ad); the Euler target is folded here first
+            if (o.flags & XF_SEED_ACTOR) xchain_fold(c, a, a.fs);
+            auto seed = [&](int rb, int) {
+                const int row = rb + c.r;
+                f32x4 d{0.f, 0.f, 0.f, 0.f};
+                if (4 * c.q < a.ad) {
+                    const f32x4 pv = ldx4(o.p0, (unsigned)((size_t)row * a.ap + 4 * c.q));
+                    if (o.flags & XF_SEED_ACTOR) {
+                        const float* ar = c.alds + (row - c.g * c.R) * 16 + 4 * c.q;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int col = 4 * c.q + t;
+                            if (col < a.ad) {
+                                const float tg = clip1(ar[t]);
+                                float g = o.f0 * (pv[t] - tg);
+                                if (pv[t] > -1.0f && pv[t] < 1.0f)
+                                    g += ldx1(o.p2, (unsigned)((size_t)row * o.i0 + o.i1 + col)) + ldx1(o.p3, (unsigned)((size_t)row * o.i0 + o.i1 + col));
+                                d[t] = g;
+                            }
+                        }
+                    } else {
+                        const f32x4 vv = ldg4(o.p1 + (size_t)row * a.ap + 4 * c.q);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (4 * c.q + t < a.ad) d[t] = o.f0 * (pv[t] - vv[t]);
+                    }
+                    if (mrel == 0) {
+                        stg4(o.o0 + (size_t)row * a.ap + 4 * c.q, d);   // dz of the head: its weight gradient reads it
+                        if ((o.flags & XF_SEED_ACTOR) && o.o1) {
+                            f32x4 tg;
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) tg[t] = (4 * c.q + t < a.ad) ? clip1(c.alds[(row - c.g * c.R) * 16 + 4 * c.q + t]) : 0.f;
+                            stg4(o.o1 + (size_t)row * a.ap + 4 * c.q, tg);
+                        }
+                    }
+                }
+                return d;
+            };
+            auto wbwd = [&](int n0, int j) { return ldg4(o.W + (size_t)(n0 + c.r) * o.ldw + 16 * j + 4 * c.q); };
+            auto epi = [&](int rb, int n0, f32x4 v) {
+                if (o.flags & XF_ZMUL) v *= ldx4(o.Zmul, xtoff(c, rb, n0 >> 4, NTN));
+                store_out(rb, n0, v);
+            };
+            xdense<1>(c, 16, o.N, ntl, mrel, rowof, seed, XNoPro{}, wbwd, epi);
+            break;
+        }
+        case XK_LNBWD: {
+            // LayerNorm backward x GELU' (utils/networks.py:56-58 reversed) of one 16-row tile per member (the columns over its four waves):
+            //   dxhat = dY gamma ; dg = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)) ; dZ = dg GELU'(z)
+            // A = dY tile-major (or XF_SYN: p0 = dq [rows, i0], W = head kernel [H][ldw]); p1 = GELU output (tile-major); Zmul = GELU'(z); ln_stats;
+            // ln_g; Ct / C = dZ
+            if (mrel >= c.RT) break;
+            const int rb = c.g * c.R + 16 * mrel, row = rb + c.r;
+            const int H = o.N, J = H >> 4;
+            float dqr = 0.f;
+            if (o.flags & XF_SYN) {
+                if (o.flags & XF_SEED_CRITIC) {   // p2 / p3 = q of the two target members, p4 = rewards, p5 = masks; o0 = dq out; f0 = discount, i1 = q_agg; f1 = 1 / B
+                    const float ta = ldx1(o.p2, (unsigned)((size_t)row * 16)), tb = ldx1(o.p3, (unsigned)((size_t)row * 16));
+                    const float nq = o.i1 ? fminf(ta, tb) : 0.5f * (ta + tb);
+                    const float y = ldg(o.p4 + row) + o.f0 * ldg(o.p5 + row) * nq;
+                    dqr = (ldx1(o.p0, (unsigned)((size_t)row * o.i0)) - y) * o.f1;
+                    if (c.wave == 0 && c.q == 0) stg(o.o0 + (size_t)row * o.i0, dqr);
+                } else {
+                    dqr = ldg(o.p0 + (size_t)row * o.i0);
+                }
+            }
+            const float mean = ldx1(o.ln_stats, 2u * (unsigned)row), rstd = ldx1(o.ln_stats, 2u * (unsigned)row + 1u);
+            f32x4 zz[8], dd[8], gm[8], gq[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j = c.wave + 4 * jj;
+                zz[jj] = gq[jj] = gm[jj] = dd[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (j < J) {
+                    zz[jj] = ldx4(o.Zmul, xtoff(c, rb, j, J));
+                    gq[jj] = ldx4(o.p1, xtoff(c, rb, j, J));
+                    gm[jj] = ldg4(o.ln_g + 16 * j + 4 * c.q);
+                    if (o.flags & XF_SYN) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dd[jj][e] = dqr * ldg(o.W + (size_t)(16 * j + 4 * c.q + e) * o.ldw);
+                    } else dd[jj] = ldx4(o.A, xtoff(c, rb, j, J));
+                }
+            }
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gq[jj][e] = (gq[jj][e] - mean) * rstd;    // xhat
+                    dd[jj][e] = dd[jj][e] * gm[jj][e];        // dxhat
+                    if (c.wave + 4 * jj < J) { s1 += dd[jj][e]; s2 += dd[jj][e] * gq[jj][e]; }
+                }
+            s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+            __syncthreads();
+            if (c.q == 0) { c.stat[(c.wave * 16 + c.r) * 2] = s1; c.stat[(c.wave * 16 + c.r) * 2 + 1] = s2; }
+            __syncthreads();
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { a1 += c.stat[(w * 16 + c.r) * 2]; a2 += c.stat[(w * 16 + c.r) * 2 + 1]; }
+            const float inv = 1.0f / (float)H;
+            const float m1 = a1 * inv, m2 = a2 * inv;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j = c.wave + 4 * jj;
+                if (j < J) {
+                    f32x4 ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[e] = rstd * (dd[jj][e] - m1 - gq[jj][e] * m2) * zz[jj][e];
+                    if (o.Ct) stg4(o.Ct + xtoff(c, rb, j, J), ov);
+                    if (o.C) stg4(o.C + (size_t)row * o.ldc + 16 * j + 4 * c.q, ov);
+                }
+            }
+            break;
+        }
+        case XK_CHAIN_L0: {
+            // layer 0 of Euler step s: GELU(C0 + [a_s | t_s] W0[act rows, t row]) with C0 = obs W0[obs rows] + b0 computed once
+            // (A = C0, tile-major; Ct = the chain's activation buffer)
+            xchain_fold(c, a, o.step);
+            auto al = [&](int rb, int) { return *reinterpret_cast<const f32x4*>(c.alds + (rb - c.g * c.R + c.r) * 16 + 4 * c.q); };
+            auto wl = [&](int n0, int) {
+                f32x4 v;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int k = a.od + 4 * c.q + t;
+                    v[t] = k < a.in_p ? ldg(a.w0 + (size_t)k * o.ldw + n0 + c.r) : 0.f;
+                }
+                return v;
+            };
+            auto epi = [&](int rb, int n0, f32x4 v) {
+                v += ldx4(o.A, xtoff(c, rb, n0 >> 4, NTN));
+                f32x4 g;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) g[t] = gelu_f(v[t]);
+                stg4(o.Ct + xtoff(c, rb, n0 >> 4, NTN), g);
+            };
+            xdense<1>(c, 16, o.N, ntl, mrel, rowof, al, XNoPro{}, wl, epi);
+            break;
+        }
+        case XK_CHAIN_MID:
+        case XK_CHAIN_LAST: {
+            const int J = o.K >> 4;
+            const f32x4* wl_base = c.wlds ? c.wlds + (size_t)o.i0 * J * 64 : nullptr;   // i0 = slot of this layer's kernel in LDS
+            auto wl = [&](int n0, int j) {
+                if (wl_base) return wl_base[j * 64 + c.lane];
+                return wfwd(n0, j);
+            };
+            auto epi = [&](int rb, int n0, f32x4 v) {
+                const int row = rb + c.r;
+                v += ldg4(o.bias + n0 + 4 * c.q);
+                f32x4 g;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) g[t] = gelu_f(v[t]);
+                if (o.kind == XK_CHAIN_MID) { stg4(o.Ct + xtoff(c, rb, n0 >> 4, NTN), g); return; }
+                // last hidden layer: this member's 16 columns times its 16 rows of the action head -> a partial of the velocity
+                f32x4 pv{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) pv = __builtin_amdgcn_mfma_f32_16x16x4f32(w4f[t], g[t], pv, 0, 0, 0);
+                if (4 * c.q < a.ad) stg4(a.vp + ((size_t)c.member * a.B + row) * 16 + 4 * c.q, pv);
+            };
+            xdense<8>(c, o.K, o.N, ntl, mrel, rowof, aload, XNoPro{}, wl, epi);
+            break;
+        }
+        case XK_METRICS: {
+            // per-XCD partial sums of the info scalars (agents/fql.py:39-44,85-92), folded by the finalize launch:
+            //   0 sum (q - y)^2 (both members)  1 sum q  2 max q  3 min q  4 sum (pred - vel)^2  5 sum (mu - tgt)^2  6 sum q2  7 sum |q2|  8 sum (clip(mu3) - a)^2
+            // p0 / p1 = critic q [B, 16], p2 / p3 = target q, p4 = rewards, p5 = masks; A = bc pred, W = vel; bias = one-step out [3B, ap];
+            // Zmul = tgt; ln_g / ln_b = q2 of the two members; ln_xout unused; o0 = w_act as const; f0 = discount, i1 = q_agg
+            if (mrel != 0 || c.wave != 0) break;
+            float sl = 0.f, sq = 0.f, mx = -INFINITY, mn = INFINITY, sbc = 0.f, sdi = 0.f, sq2 = 0.f, sa2 = 0.f, sms = 0.f;
+            for (int lr = c.lane; lr < c.R; lr += 64) {
+                const int row = c.g * c.R + lr;
+                const float ta = ldx1(o.p2, (unsigned)row * 16u), tb = ldx1(o.p3, (unsigned)row * 16u);
+                const float nq = o.i1 ? fminf(ta, tb) : 0.5f * (ta + tb);
+                const float y = ldg(o.p4 + row) + o.f0 * ldg(o.p5 + row) * nq;
+                const float qa = ldx1(o.p0, (unsigned)row * 16u), qb = ldx1(o.p1, (unsigned)row * 16u);
+                sl += (qa - y) * (qa - y) + (qb - y) * (qb - y);
+                sq += qa + qb; mx = fmaxf(mx, fmaxf(qa, qb)); mn = fminf(mn, fminf(qa, qb));
+                const float q2 = 0.5f * (ldx1(o.ln_g, (unsigned)row * 16u) + ldx1(o.ln_b, (unsigned)row * 16u));
+                sq2 += q2; sa2 += fabsf(q2);
+                for (int col = 0; col < a.ad; ++col) {
+                    const float db = ldx1(o.A, (unsigned)(row * a.ap + col)) - ldg(o.W + (size_t)row * a.ap + col);
+                    sbc += db * db;
+                    const float dd = ldx1(o.bias, (unsigned)((a.B + row) * a.ap + col)) - ldx1(o.Zmul, (unsigned)(row * a.ap + col));
+                    sdi += dd * dd;
+                    const float dm = clip1(ldx1(o.bias, (unsigned)((2 * a.B + row) * a.ap + col))) - ldg(o.o0 + (size_t)row * a.ap + col);
+                    sms += dm * dm;
+                }
+            }
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                sl += __shfl_xor(sl, off); sq += __shfl_xor(sq, off); sbc += __shfl_xor(sbc, off); sdi += __shfl_xor(sdi, off);
+                sq2 += __shfl_xor(sq2, off); sa2 += __shfl_xor(sa2, off); sms += __shfl_xor(sms, off);
+                mx = fmaxf(mx, __shfl_xor(mx, off)); mn = fminf(mn, __shfl_xor(mn, off));
+            }
+            if (c.lane == 0) {
+                float* xp = a.xpart + 16 * c.g;
+                stg(xp + 0, sl); stg(xp + 1, sq); stg(xp + 2, mx); stg(xp + 3, mn); stg(xp + 4, sbc); stg(xp + 5, sdi); stg(xp + 6, sq2); stg(xp + 7, sa2); stg(xp + 8, sms);
+            }
+            break;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void fql_xcd_kernel(const XcdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float xlds[];
+    XCtx c;
+    c.lane = threadIdx.x & 63; c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    c.r = c.lane & 15; c.q = c.lane >> 4;
+    c.R = a.R; c.RT = a.RT; c.st2 = nullptr;
+    c.g = (int)(__builtin_amdgcn_s_getreg(6164) & 7u);   // HW_REG_XCC_ID[3:0]: the XCD this workgroup runs on
+    c.red = reinterpret_cast<f32x4*>(xlds);                       // 16 x 64 float4
+    c.stat = xlds + 16 * 64 * 4;                                  // 4 x 4 x 16 x 2
+    c.alds = c.stat + 512;                                        // [R][16]
+    float* misc = c.alds + XCD_MAXROWS * 16;                      // 16 words
+    f32x4* wl = reinterpret_cast<f32x4*>(misc + 16);
+    c.wlds = a.chain_nl > 0 ? wl : nullptr;
+    FQL_GAS unsigned* cnt = (FQL_GAS unsigned*)(a.sync + 32 * c.g);
+    FQL_GAS unsigned* err = (FQL_GAS unsigned*)(a.sync + 32 * 16);
+    if (threadIdx.x == 0) {
+        reinterpret_cast<unsigned*>(misc)[0] = __hip_atomic_fetch_add((FQL_GAS unsigned*)(a.sync + 32 * (8 + c.g)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        reinterpret_cast<unsigned*>(misc)[1] = 0u;   // "a wait of this workgroup timed out"
+    }
+    __syncthreads();
+    c.member = __builtin_amdgcn_readfirstlane((int)reinterpret_cast<unsigned*>(misc)[0]);   // (an LDS read: uniform, but only this tells the compiler)
+    if (c.member >= XCD_NMEM) {   // more than 32 workgroups on this XCD: not a placement this kernel runs on
+        if (threadIdx.x == 0) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    // the Euler chain's hidden kernels: this member's 16 output columns of each, fragment-major, resident for the whole launch
+    const int JH = a.H >> 4;
+    if (c.wlds && 16 * c.member < a.H) {
+        for (int l = 0; l < a.chain_nl; ++l)
+            for (int i = threadIdx.x; i < JH * 64; i += 256) {
+                const int j = i >> 6, ln = i & 63, rr = ln & 15, qq = ln >> 4;
+                f32x4 v;
+                const float* p = a.chain_w[l] + (size_t)(16 * j + 4 * qq) * a.H + 16 * c.member + rr;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = ldg(p + (size_t)t * a.H);
+                wl[((size_t)l * JH + j) * 64 + ln] = v;
+            }
+    }
+    // this member's 16 rows of the action head as the first MFMA operand of the partial product: lane (n, q) holds W4[16 member + 4 q + t][n]
+    float w4f[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int k = 16 * c.member + 4 * c.q + t;
+        w4f[t] = (a.w4 && k < a.H && c.r < a.ap) ? ldg(a.w4 + (size_t)k * a.ap + c.r) : 0.f;
+    }
+    __syncthreads();
+    bool dead = false;
+    for (int p = 0; p < a.nphase; ++p) {
+        if (p > 0) {
+            if (threadIdx.x == 0) {
+                const unsigned want = (unsigned)XCD_NMEM * (unsigned)p;
+                unsigned spins = 0;
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        reinterpret_cast<unsigned*>(misc)[1] = 1u;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            if (__builtin_amdgcn_readfirstlane((int)reinterpret_cast<unsigned*>(misc)[1])) dead = true;
+        }
+        if (dead) break;   // (uniform: every thread read the same LDS word behind the barrier)
+#ifdef FQL_XSTAMPS
+        unsigned long long* stp = a.stamps + ((size_t)blockIdx.x * a.nphase + p) * 4;
+        if (threadIdx.x == 0) stp[0] = __builtin_amdgcn_s_memrealtime();
+#endif
+        XPhase ph;
+        ph.first = *(const __attribute__((address_space(4))) int*)&a.phases[p].first;
+        ph.count = *(const __attribute__((address_space(4))) int*)&a.phases[p].count;
+#ifdef FQL_XSTAMPS
+        c.st2 = (p == a.stamp_phase) ? a.stamps2 + (size_t)blockIdx.x * 16 : nullptr;
+        XST(c, 8);
+#endif
+        for (int oi = ph.first; oi < ph.first + ph.count; ++oi) xrun(c, a, a.ops + oi, w4f);
+        XST(c, 7);
+#ifdef FQL_XSTAMPS
+        if (threadIdx.x == 0) stp[1] = __builtin_amdgcn_s_memrealtime();
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every store of this phase has reached the L2 ...
+        __syncthreads();
+#ifdef FQL_XSTAMPS
+        if (threadIdx.x == 0) stp[2] = __builtin_amdgcn_s_memrealtime();
+#endif
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before this member counts as arrived
+#ifdef FQL_XSTAMPS
+        if (threadIdx.x == 0) { stp[3] = __builtin_amdgcn_s_memrealtime(); a.stamps[((size_t)blockIdx.x * a.nphase) * 4 + 3] = (unsigned long long)((c.g << 8) | c.member); }
+#endif
+    }
+}
+
+#define FQL_XCD_LDS_FLOATS(chain_nl, H) (16 * 64 * 4 + 512 + XCD_MAXROWS * 16 + 16 + (chain_nl) * ((H) / 16) * 64 * 4)
