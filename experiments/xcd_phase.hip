@@ -35,11 +35,18 @@ __device__ __forceinline__ float gelu_f(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// mode bit 4: the four waves synchronise through a counter in LDS (the two-team kernel's xsync) instead of s_barrier
+#define SYNC() do { if (a.mode & 16) { bt += 4u; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < bt) { if (a.mode & 32) __builtin_amdgcn_s_sleep(1); } asm volatile("" ::: "memory"); } else __syncthreads(); } while (0)
 template <int RT>
 __global__ __launch_bounds__(256) void xcd_chain(Args a) {
     extern __shared__ __attribute__((aligned(16))) f32x4 lds[];   // [3][2048] weights, [4][RT][64] reduce
     __shared__ unsigned s_member;
+    __shared__ unsigned s_bar;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned bt = 0u;
+    __attribute__((address_space(3))) unsigned* bar = (__attribute__((address_space(3))) unsigned*)&s_bar;
+    if (tid == 0) s_bar = 0u;
     const unsigned xcc = (a.mode & 8) ? (blockIdx.x & 7) : __builtin_amdgcn_s_getreg(6164);   // HW_REG_XCC_ID[3:0]
     if (tid == 0) {
         s_member = __hip_atomic_fetch_add((GAS unsigned*)(a.ticket + 32 * xcc), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -65,7 +72,7 @@ __global__ __launch_bounds__(256) void xcd_chain(Args a) {
                     if (++spins > 4000000u) { *a.err = 2; break; }
                 }
             }
-            __syncthreads();
+            SYNC();
         }
         if (tid == 0) st[p * 4 + 0] = __builtin_amdgcn_s_memtime();
         const float* src = a.act[p & 1] + xcc * gstride;
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(256) void xcd_chain(Args a) {
         if (tid == 0) st[p * 4 + 1] = __builtin_amdgcn_s_memtime();
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) red[(w * RT + rt) * 64 + lane] = acc[rt];
-        __syncthreads();
+        SYNC();
         for (int o = tid; o < RT * 64; o += 256) {   // o = rt * 64 + lane'
             f32x4 s = red[o];
 #pragma unroll
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(256) void xcd_chain(Args a) {
         }
         if (tid == 0) st[p * 4 + 2] = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        SYNC();
         if (tid == 0) {
             __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             st[p * 4 + 3] = __builtin_amdgcn_s_memtime();

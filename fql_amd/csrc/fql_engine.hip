@@ -1967,7 +1967,7 @@ struct fql_engine {
                 FQL_LAUNCH(fql_wfrag_kernel, dim3(wfrag_grid), dim3(FQL_THREADS), 0, s, (const WfragTask*)d_wfrag, wfrag_n, tl);
                 break;
             case OP_XCD:   // one workgroup per CU: 8 XCDs x 32 members
-                FQL_LAUNCH(fql_xcd_kernel, dim3(XCD_NGRP * XCD_NMEM), dim3(256), x_lds, s, L.op.xcd);
+                FQL_LAUNCH(fql_xcd_kernel, dim3(XCD_NGRP * XCD_NMEM), dim3(512), x_lds, s, L.op.xcd);
                 break;
             case OP_ADAM: {
                 AdamArgs a{P, G, Mu, Nu, P + n_train, d_chunks, d_state, d_partials, L.op.adam_c0, (int)critic_size, cfg.lr, cfg.tau, tl,
@@ -2779,7 +2779,8 @@ struct fql_engine {
         XOp op{};
         std::vector<const void*> reads, writes;
         int level = 0;
-        bool chain = false;
+        bool chain = false;   // team 0: the critical path (C0, Euler chain, one-step actor's backward); everything else is team 1's
+        int wait = 0;         // phases of the OTHER team that must be complete first
         double macs = 0.0;
     };
     bool xcd_eligible() const {
@@ -3047,7 +3048,11 @@ struct fql_engine {
             for (int e = 0; e < 2; ++e) x_backward(xe, p_c2[e], 0, true, 0, 16 + 8 * e, false);   // dQ/da: what the one-step actor's backward waits for
             for (int e = 0; e < 2; ++e) x_backward(xe, p_c1[e], 0, false, 1, 8 * e, true);
             x_backward(xe, p_bc, 0, false, 2, 0, true);
-            x_backward(xe, p_os_bwd, B, false, 3, 0, true);
+            {
+                const size_t first = xe.size();
+                x_backward(xe, p_os_bwd, B, false, 3, 0, true);
+                for (size_t i = first; i < xe.size(); ++i) xe[i].chain = true;   // the tail of the critical path
+            }
             {   // info scalars: per-XCD partial sums
                 XEmit e;
                 XOp& o = e.op;
@@ -3059,40 +3064,59 @@ struct fql_engine {
                 e.writes = {xpart};
                 xe.push_back(e);
             }
-            // levels: an op runs one phase after everything it conflicts with (RAW, WAW, WAR)
+            // phases: an op runs one phase of ITS team after every op of that team it conflicts with (RAW, WAW, WAR), and its phase waits for
+            // the phase of every op of the other team it conflicts with
             {
                 std::map<const void*, int> last_writer;
                 std::map<const void*, std::vector<int>> readers;
+                std::vector<int> waitmax[2];   // per team and phase: how many phases of the other team it waits for
                 for (int i = 0; i < (int)xe.size(); ++i) {
                     XEmit& e = xe[i];
-                    int lv = 0;
-                    for (const void* r : e.reads) { auto it = last_writer.find(r); if (it != last_writer.end()) lv = std::max(lv, xe[it->second].level + 1); }
+                    int lv = 0, wt = 0;
+                    auto dep = [&](int d) {
+                        if (d == i) return;
+                        if (xe[d].chain == e.chain) lv = std::max(lv, xe[d].level + 1);
+                        else wt = std::max(wt, xe[d].level + 1);
+                    };
+                    for (const void* r : e.reads) { auto it = last_writer.find(r); if (it != last_writer.end()) dep(it->second); }
                     for (const void* w : e.writes) {
-                        auto it = last_writer.find(w); if (it != last_writer.end()) lv = std::max(lv, xe[it->second].level + 1);
-                        auto ir = readers.find(w); if (ir != readers.end()) for (int r : ir->second) if (r != i) lv = std::max(lv, xe[r].level + 1);
+                        auto it = last_writer.find(w); if (it != last_writer.end()) dep(it->second);
+                        auto ir = readers.find(w); if (ir != readers.end()) for (int r : ir->second) dep(r);
                     }
-                    e.level = lv;
+                    // no cycles between the teams: the phases of the other team this op waits for must not themselves wait for this op's phase,
+                    // so the op goes behind every phase of its own team that they wait for
+                    const int me = e.chain ? 0 : 1, other = 1 - me;
+                    for (int q = 0; q < wt && q < (int)waitmax[other].size(); ++q) lv = std::max(lv, waitmax[other][q]);
+                    e.level = lv; e.wait = wt;
+                    if ((int)waitmax[me].size() <= lv) waitmax[me].resize(lv + 1, 0);
+                    waitmax[me][lv] = std::max(waitmax[me][lv], wt);
                     for (const void* r : e.reads) readers[r].push_back(i);
                     for (const void* w : e.writes) { last_writer[w] = i; readers.erase(w); }
                 }
             }
-            int maxlv = 0;
-            for (const XEmit& e : xe) maxlv = std::max(maxlv, e.level);
             std::vector<XOp> ops;
             std::vector<XPhase> phases;
             double macs = 0.0;
-            for (int lv = 0; lv <= maxlv; ++lv) {
-                XPhase ph{(int)ops.size(), 0};
-                for (int pass = 0; pass < 2; ++pass)
+            int nph[2] = {0, 0};
+            for (int team = 0; team < 2; ++team) {
+                int maxlv = -1;
+                for (const XEmit& e : xe) if (e.chain == (team == 0)) maxlv = std::max(maxlv, e.level);
+                int waited = 0;   // (a team's phases run in order: a wait already made covers the later ones)
+                for (int lv = 0; lv <= maxlv; ++lv) {
+                    XPhase ph{(int)ops.size(), 0, 0, 0};
                     for (const XEmit& e : xe)
-                        if (e.level == lv && e.chain == (pass == 0)) { ops.push_back(e.op); ph.count++; }
-                phases.push_back(ph);
+                        if (e.chain == (team == 0) && e.level == lv) { ops.push_back(e.op); ph.count++; ph.wait_count = std::max(ph.wait_count, e.wait); }
+                    if (ph.wait_count <= waited) ph.wait_count = 0; else waited = ph.wait_count;
+                    if (team == 0 && ph.count == 1 && ops[ph.first].kind == XK_CHAIN_L0 && ops[ph.first].step == 0) ph.chain = fs * nh;
+                    phases.push_back(ph);
+                }
+                nph[team] = maxlv + 1;
             }
             for (const XEmit& e : xe) macs += e.macs;
             if (getenv("FQL_DUMP")) {
-                fprintf(stderr, "[fql] xcd program: %zu ops in %zu phases\n", ops.size(), phases.size());
+                fprintf(stderr, "[fql] xcd program: %zu ops, team 0: %d phases, team 1: %d phases\n", ops.size(), nph[0], nph[1]);
                 for (size_t pi = 0; pi < phases.size(); ++pi) {
-                    fprintf(stderr, "[fql]  phase %2zu:", pi);
+                    fprintf(stderr, "[fql]  team %d phase %2d (waits for %2d of the other):", pi < (size_t)nph[0] ? 0 : 1, (int)(pi < (size_t)nph[0] ? pi : pi - nph[0]), phases[pi].wait_count);
                     for (int i = phases[pi].first; i < phases[pi].first + phases[pi].count; ++i) fprintf(stderr, " k%d(%dx%d,f%x)", ops[i].kind, ops[i].K, ops[i].N, ops[i].flags);
                     fprintf(stderr, "\n");
                 }
@@ -3107,24 +3131,28 @@ struct fql_engine {
             XcdArgs& a = xo.xcd;
             a.ops = (const XOp*)up(ops.data(), ops.size() * sizeof(XOp));
             a.phases = (const XPhase*)up(phases.data(), phases.size() * sizeof(XPhase));
-            a.nphase = (int)phases.size();
+            a.nphase0 = nph[0]; a.nphase1 = nph[1];
             a.B = B; a.R = B / 8; a.RT = B / 128;
             a.sync = xsync; a.xpart = xpart;
             a.chain_nl = nh - 1; a.H = H;
             if ((size_t)FQL_XCD_LDS_FLOATS(a.chain_nl, H) * sizeof(float) > 160 * 1024) a.chain_nl = 0;   // (deeper nets: the chain streams its kernels like every other pass)
-            for (int l = 1; l < nh && l - 1 < 7; ++l) a.chain_w[l - 1] = P + nb.layers[l].w;
+            for (int l = 1; l < nh && l - 1 < 7; ++l) { a.chain_w[l - 1] = P + nb.layers[l].w; a.chain_b[l - 1] = P + nb.layers[l].b; }
+            a.hc[0] = Hc[0]; a.hc[1] = Hc[1]; a.c0 = C0;
             a.w0 = P + nb.layers[0].w; a.w4 = P + nb.layers[nh].w; a.b4 = P + nb.layers[nh].b;
             a.x_eu = X_eu; a.vp = xvp; a.tgt = tgt;
             a.od = od; a.ad = ad; a.ap = ap; a.in_p = inp_b; a.fs = fs;
             a.lds_floats = FQL_XCD_LDS_FLOATS(a.chain_nl, H);
+            a.skip_team = getenv("FQL_XCD_SKIP_TEAM") ? atoi(getenv("FQL_XCD_SKIP_TEAM")) : -1;
 #ifdef FQL_XSTAMPS
-            a.stamps = (unsigned long long*)dalloc(ws_allocs, ((size_t)256 * phases.size() * 4 + 256 * 16) * 2);
-            a.stamps2 = a.stamps + (size_t)256 * phases.size() * 4;
+            a.stamp_stride = std::max(nph[0], nph[1]);
+            a.stamps = (unsigned long long*)dalloc(ws_allocs, ((size_t)512 * a.stamp_stride * 4 + 256 * 25) * 2);
+            a.stamps2 = a.stamps + (size_t)512 * a.stamp_stride * 4;
             a.stamp_phase = getenv("FQL_XSTAMP_PHASE") ? atoi(getenv("FQL_XSTAMP_PHASE")) : -1;
+            a.stamp_team = getenv("FQL_XSTAMP_TEAM") ? atoi(getenv("FQL_XSTAMP_TEAM")) : 0;
             if (mode == 0) x_stamps = a.stamps;
 #endif
             x_lds = (size_t)a.lds_floats * sizeof(float);
-            x_nphase = a.nphase; x_nops = (int)ops.size();
+            x_nphase = std::max(nph[0], nph[1]); x_nops = (int)ops.size();
             xo.reads = {X_os, X_bc, X_eu, X_c1, X_c2, X_ct, vel, w_rew, w_mask, w_act, X_e0};
             for (const XEmit& e : xe) for (const void* w : e.writes) xo.writes.push_back(w);
             xo.fin_mode = 0;
@@ -3280,13 +3308,13 @@ struct fql_engine {
         launches_per_update = prog_full.exec ? (int64_t)prog_full.launches.size()
                                              : (int64_t)prog_fwdbwd.launches.size() + (int64_t)prog_opt.launches.size();
         if (xcd_eligible()) {
-            xsync = (unsigned*)dalloc(W, 17 * 32); xpart = dalloc(W, 8 * 16); xvp = dalloc(W, (size_t)XCD_NMEM * B * 16);
+            xsync = (unsigned*)dalloc(W, 32 * 32); xpart = dalloc(W, 8 * 16); xvp = dalloc(W, (size_t)XCD_NMEM * B * 16);
             build_xcd_program(prog_xfull, 0);
             build_xcd_program(prog_xbegin, 1);
             build_xcd_program(prog_xopt, 2);
             HIP_CHECK(hipFuncSetAttribute((const void*)fql_xcd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x_lds));
             int per_cu = 0;   // every workgroup waits for its XCD's other 31: all 256 must be resident, one per CU
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fql_xcd_kernel, 256, x_lds) != hipSuccess || per_cu < 1) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fql_xcd_kernel, 512, x_lds) != hipSuccess || per_cu < 1) {
                 (void)hipGetLastError();
             } else {
                 schedule(prog_xfull, W); schedule(prog_xbegin, W); schedule(prog_xopt, W);
@@ -4267,11 +4295,18 @@ extern "C" int fql_profile_update(fql_handle h, int batch_size, int cap, int* ty
     catch (const HipError& e) { h->prof_a = h->prof_b = nullptr; h->err = e.msg; return FQL_E_HIP; }
 }
 
+// Diagnostic only: the sticky error word of the XCD-resident launch (0 = fine, 1 = a wait timed out, 2 = more than 32 workgroups on an XCD)
+extern "C" int fql_debug_xcd_err(fql_handle h, unsigned* out) {
+    if (!h || !h->xsync || !out) return FQL_E_NOTFOUND;
+    if (hipDeviceSynchronize() != hipSuccess) return FQL_E_HIP;
+    return hipMemcpy(out, h->xsync + 16 * 32, 4, hipMemcpyDeviceToHost) == hipSuccess ? FQL_OK : FQL_E_HIP;
+}
+
 // Diagnostic only (-DFQL_XSTAMPS builds): the phase stamps of the last XCD-resident launch, [256][phases][4] ticks of 10 ns
 extern "C" int fql_debug_xcd_stamps(fql_handle h, unsigned long long* out, size_t cap, int* nphase) {
     if (!h || !h->x_stamps) return FQL_E_NOTFOUND;
     if (nphase) *nphase = h->x_nphase;
-    const size_t n = (size_t)256 * h->x_nphase * 4 + 256 * 16;
+    const size_t n = (size_t)512 * h->x_nphase * 4 + 256 * 25;
     if (cap < n) return FQL_E_INVALID;
     if (hipDeviceSynchronize() != hipSuccess) return FQL_E_HIP;
     return hipMemcpy(out, h->x_stamps, n * 8, hipMemcpyDeviceToHost) == hipSuccess ? FQL_OK : FQL_E_HIP;

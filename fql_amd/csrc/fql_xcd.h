@@ -70,17 +70,24 @@ struct XOp {
     float f0, f1;
 };
 
-struct XPhase { int first, count; };
+// One phase of one team: ops [first, first + count), run after every member of this XCD has finished the team's previous phase and -
+// where wait_count > 0 - after the OTHER team's members have finished their phase wait_count - 1.
+// chain > 0: this phase opens the Euler chain - `chain` phases of one chain op each, which team 0 runs on a dedicated path (xchain_block).
+struct XPhase { int first, count, wait_count, chain; };
 
 struct XcdArgs {
     const XOp* ops;
-    const XPhase* phases;
-    int nphase;
+    const XPhase* phases;    // team 0's phases [0, nphase0), then team 1's [nphase0, nphase0 + nphase1)
+    int nphase0, nphase1;
     int B, R, RT;            // batch, rows per XCD, 16-row tiles per XCD
-    unsigned* sync;          // [0, 8): arrival counters (32 words apart), [8, 16): tickets, word 16 * 32: error flag; zeroed by the prep launch
+    unsigned* sync;          // slots of 32 words: [0, 8) team 0's arrival flags per XCD (one word per member), [8, 16) tickets, [16] error flag (sticky),
+                             // [17, 25) team 1's arrival flags; all but the error flag zeroed by the prep launch
     float* xpart;            // [8][16] per-XCD partial sums of the info scalars
     // Euler chain (agents/fql.py:155-171)
     const float* chain_w[7]; // hidden kernels 1 .. nh - 1 of the BC flow, [H][H]
+    const float* chain_b[7]; // their biases
+    float* hc[2];            // the chain's activation buffers (tile-major, ping-pong)
+    const float* c0;         // obs W0[obs rows] + b0 (tile-major), loop invariant
     int chain_nl;            // how many of them (LDS resident: chain_nl * H * 64 bytes)
     int H;                   // hidden width of the BC flow
     const float* w0;         // its first kernel [in_p][H]: rows od .. od + 15 are the rank-16 update of layer 0
@@ -91,9 +98,10 @@ struct XcdArgs {
     float* tgt;              // [B, ap] clip(Euler result) (written by member 0 for the metrics / debugging)
     int od, ad, ap, in_p, fs;
     int lds_floats;
-    unsigned long long* stamps2;  // diagnostics build: [256][16] stamps inside the ops of phase `stamp_phase`
-    int stamp_phase;
-    unsigned long long* stamps;   // diagnostics build (-DFQL_XSTAMPS): [256 workgroups][phases][4] s_memrealtime ticks (10 ns): wait over, ops done, drained, arrived
+    unsigned long long* stamps2;  // diagnostics build: [256][16] stamps inside the ops of phase `stamp_phase` of team `stamp_team` (+ [256] placement words)
+    int stamp_phase, stamp_team, stamp_stride;
+    int skip_team;                // diagnostics: ops of this team are not executed (results invalid); -1 = none
+    unsigned long long* stamps;   // diagnostics build (-DFQL_XSTAMPS): [256 workgroups][2 teams][stamp_stride phases][4] s_memrealtime ticks (10 ns): wait over, ops done, drained, arrived
 };
 
 __device__ __forceinline__ f32x4 ldx4(const float* base, unsigned off) {   // 16-byte load that bypasses this CU's L1 (sc1): data another CU of the XCD wrote
@@ -106,19 +114,36 @@ __device__ __forceinline__ float ldx1(const float* base, unsigned off) {
 }
 
 struct XCtx {
-    int g, member, wave, lane, r, q;
+    int g, member, wave, lane, r, q;   // wave: 0..3 inside the team
+    int team, tid;                     // tid: 0..255 inside the team
     int R, RT;
+    unsigned bt;                       // this wave's count of team barriers (x 4)
+    __attribute__((address_space(3))) unsigned* bar;   // the team's barrier word in LDS
     f32x4* red;     // [4 waves][4 tiles][64] cross-wave reduction
     float* stat;    // [4 waves][4 tiles][16 rows][2]
     float* alds;    // [R][16] current Euler actions (+ t column)
     const f32x4* wlds;
     unsigned long long* st2;
+    unsigned long long* stl;   // 16 stamps in LDS
+    unsigned long long tw[6];  // diagnostics: ticks spent in poll / barrier after poll / arrive-drain / arrive-barrier / count
 };
 #ifdef FQL_XSTAMPS
-#define XST(c, k) do { if ((c).st2 && threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); (c).st2[k] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+// stamps go to LDS (flushed at the end of the phase): a global store per stamp would put its round trip into the next stamp's wait
+#define XST(c, k) do { if ((c).st2 && (c).tid == 0) { if ((k) == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); (c).stl[k] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define XST(c, k) do {} while (0)
 #endif
+
+// Barrier of the four waves of a team.  A workgroup holds two teams that run different programs, so s_barrier (all eight waves) is
+// of no use: the waves count up a word in LDS and spin on it.  LDS operations of a wave complete in order, so the lgkmcnt(0) wait in
+// front makes everything it wrote to LDS visible before it counts as arrived.
+__device__ __forceinline__ void xsync(XCtx& c) {
+    c.bt += 4u;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (c.lane == 0) __hip_atomic_fetch_add(c.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(c.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < c.bt) __builtin_amdgcn_s_sleep(1);   // (a bare spin takes LDS and issue slots from the other team)
+    asm volatile("" ::: "memory");
+}
 
 // row base (global row of the [rows, ld] buffers) of tile ti of an op
 __device__ __forceinline__ int xrow(const XCtx& c, const XOp& o, int ti) {
@@ -131,7 +156,7 @@ __device__ __forceinline__ int xrow(const XCtx& c, const XOp& o, int ti) {
 // (compile time: a conditional MFMA makes the compiler shuttle accumulators between register files around every product) share a
 // weight fragment; partial accumulators meet in LDS and wave u finishes row tile u.  Slices beyond K load zeros.
 template <int NT, int NJ, class RowOf, class ALoad, class Pro, class WLoad, class Epi>
-__device__ __forceinline__ void xdense_nt(const XCtx& c, int K, int N, int ntl, int mrel, RowOf rowof, ALoad aload, Pro pro, WLoad wload, Epi epi) {
+__device__ __forceinline__ void xdense_nt(XCtx& c, int K, int N, int ntl, int mrel, RowOf rowof, ALoad aload, Pro pro, WLoad wload, Epi epi) {
     const int J = K >> 4, ntn = N >> 4;
     for (int ct = mrel; ct < ntn; ct += XCD_NMEM) {
         const int n0 = ct << 4;
@@ -170,10 +195,10 @@ __device__ __forceinline__ void xdense_nt(const XCtx& c, int K, int N, int ntl, 
 #pragma unroll
                     for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[jj][t], av[u][jj][t], acc[u], 0, 0, 0);
             XST(c, 4);
-            __syncthreads();
+            xsync(c);
 #pragma unroll
             for (int u = 0; u < NT; ++u) c.red[(c.wave * 4 + u) * 64 + c.lane] = acc[u];
-            __syncthreads();
+            xsync(c);
             XST(c, 5);
             if (c.wave < NT) {
                 f32x4 s = c.red[(0 * 4 + c.wave) * 64 + c.lane];
@@ -189,7 +214,7 @@ __device__ __forceinline__ void xdense_nt(const XCtx& c, int K, int N, int ntl, 
     }
 }
 template <int NJ, class RowOf, class ALoad, class Pro, class WLoad, class Epi>
-__device__ __forceinline__ void xdense(const XCtx& c, int K, int N, int ntl, int mrel, RowOf rowof, ALoad aload, Pro pro, WLoad wload, Epi epi) {
+__device__ __forceinline__ void xdense(XCtx& c, int K, int N, int ntl, int mrel, RowOf rowof, ALoad aload, Pro pro, WLoad wload, Epi epi) {
     if (ntl & 1) xdense_nt<1, NJ>(c, K, N, ntl, mrel, rowof, aload, pro, wload, epi);
     else xdense_nt<2, NJ>(c, K, N, ntl, mrel, rowof, aload, pro, wload, epi);
 }
@@ -202,7 +227,7 @@ struct XNoPro {
 // LayerNorm of the A panel in registers (utils/networks.py:58): every member needs every row's statistics and has the whole row
 // (a K-quarter per wave), so each computes them itself - no partial-sum buffers, no extra phase.
 struct XLnPro {
-    const XCtx& c;
+    XCtx& c;
     const XOp& o;
     template <int NT, int NJ>
     __device__ __forceinline__ void operator()(f32x4 (&av)[NT][NJ], const int (&rb)[NT], int J, int ct) const {
@@ -217,12 +242,12 @@ struct XLnPro {
             s1[u] += __shfl_xor(s1[u], 16); s1[u] += __shfl_xor(s1[u], 32);
             s2[u] += __shfl_xor(s2[u], 16); s2[u] += __shfl_xor(s2[u], 32);
         }
-        __syncthreads();   // (the statistics slots of the previous pass have been read)
+        xsync(c);   // (the statistics slots of the previous pass have been read)
         if (c.q == 0) {
 #pragma unroll
             for (int u = 0; u < NT; ++u) { c.stat[((c.wave * 4 + u) * 16 + c.r) * 2] = s1[u]; c.stat[((c.wave * 4 + u) * 16 + c.r) * 2 + 1] = s2[u]; }
         }
-        __syncthreads();
+        xsync(c);
         const float inv = 1.0f / (float)o.K;
         const bool store_all = (o.N >> 4) == 1;   // a single-tile op (the scalar / action heads): its one member stores the whole normalised panel
 #pragma unroll
@@ -256,18 +281,19 @@ struct XLnPro {
 // a_s = a_{s-1} + (sum of the 32 members' head partials of step s - 1 + head bias) / flow_steps, t column := s / flow_steps
 // (agents/fql.py:166-169); every member folds for itself (the partials are [32][rows][16] floats, of which act_dim columns are live) and
 // keeps the actions of its XCD's rows in LDS.  s = 0: the noise z.
-__device__ __forceinline__ void xchain_fold(const XCtx& c, const XcdArgs& a, int s) {
+__device__ __forceinline__ void xchain_fold(XCtx& c, const XcdArgs& a, int s) {
     const int nq = (a.ad + 3) >> 2;   // live column quads of a partial row
     if (s == 0) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < c.R * 16; e += 256) {
+        xsync(c);
+        for (int e = c.tid; e < c.R * 16; e += 256) {
             const int row = e >> 4, col = e & 15;
             c.alds[e] = col < a.ad ? ldg(a.x_eu + (size_t)(c.g * c.R + row) * a.in_p + a.od + col) : 0.f;
         }
-        __syncthreads();
+        xsync(c);
         return;
     }
     const float inv = 1.0f / (float)a.fs;
+    XST(c, 9);
     for (int t0 = 0; t0 < c.RT; t0 += 4) {
         const int nt = min(4, c.RT - t0);
         f32x4 pa[4];
@@ -282,11 +308,13 @@ __device__ __forceinline__ void xchain_fold(const XCtx& c, const XcdArgs& a, int
                 }
             }
         }
-        __syncthreads();
+        XST(c, 10);
+        xsync(c);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (u < nt) c.red[(c.wave * 4 + u) * 64 + c.lane] = pa[u];
-        __syncthreads();
+        xsync(c);
+        XST(c, 11);
         if (c.wave < nt) {
             f32x4 v = c.red[(0 * 4 + c.wave) * 64 + c.lane];
 #pragma unroll
@@ -300,14 +328,15 @@ __device__ __forceinline__ void xchain_fold(const XCtx& c, const XcdArgs& a, int
             }
         }
     }
-    __syncthreads();
+    xsync(c);
+    XST(c, 12);
 }
 
 // ---- one op of a phase ---------------------------------------------------------------------------------------------------------------
 // offset (floats) of lane (r, q)'s 16 bytes of tile (row base rb, column tile ct) of a tile-major [rows, 16 ntn] tensor
 __device__ __forceinline__ unsigned xtoff(const XCtx& c, int rb, int ct, int ntn) { return (unsigned)((((rb >> 4) * ntn + ct) << 8) + (c.lane << 2)); }
 
-__device__ __forceinline__ void xrun(const XCtx& c, const XcdArgs& a, const XOp* op, const float (&w4f)[4]) {
+__device__ __forceinline__ void xrun(XCtx& c, const XcdArgs& a, const XOp* op, const float (&w4f)[4]) {
     // the op table is constant for the launch: read through the constant address space, so every field is a scalar load into SGPRs
     // (as generic global loads they come back in VGPRs, and every buffer load whose descriptor is built from one gets a waterfall loop)
     XOp o;
@@ -476,9 +505,9 @@ __device__ __forceinline__ void xrun(const XCtx& c, const XcdArgs& a, const XOp*
                 }
             s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
             s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
-            __syncthreads();
+            xsync(c);
             if (c.q == 0) { c.stat[(c.wave * 16 + c.r) * 2] = s1; c.stat[(c.wave * 16 + c.r) * 2 + 1] = s2; }
-            __syncthreads();
+            xsync(c);
             float a1 = 0.f, a2 = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) { a1 += c.stat[(w * 16 + c.r) * 2]; a2 += c.stat[(w * 16 + c.r) * 2 + 1]; }
@@ -586,27 +615,216 @@ __device__ __forceinline__ void xrun(const XCtx& c, const XcdArgs& a, const XOp*
     }
 }
 
-__global__ __launch_bounds__(256, 1) void fql_xcd_kernel(const XcdArgs a) {
+// Arrival flags instead of a counter: member m stores its phase count into word m of its XCD's flag line (a plain store: it stays in the
+// XCD's L2, like the activations), and a waiting team polls the 32 words with ONE 32-lane sc1 load of that line.  An agent-scope atomic
+// executes at the memory side, not in the L2: counter arrivals measured 1.4 us from the last arrival to the poll that sees it, twice a phase's
+// matrix work.  want / want_o: phases every member must have completed with this team / the other team; true = timed out.
+__device__ __forceinline__ bool xwait(XCtx& c, const unsigned* flags, const unsigned* flags_other, unsigned want, unsigned want_o, FQL_GAS unsigned* err, unsigned* misc) {
+#ifdef FQL_XSTAMPS
+    const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (c.wave == 0) {
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+            if (c.lane < XCD_NMEM) {
+                ok = __builtin_bit_cast(unsigned, ldx1(reinterpret_cast<const float*>(flags), (unsigned)c.lane)) >= want;
+                if (want_o) ok = ok && __builtin_bit_cast(unsigned, ldx1(reinterpret_cast<const float*>(flags_other), (unsigned)c.lane)) >= want_o;
+            }
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 22) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                if (c.lane == 0) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); misc[1 + c.team] = 1u; }
+                break;
+            }
+        }
+    }
+#ifdef FQL_XSTAMPS
+    const unsigned long long tw1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    xsync(c);
+#ifdef FQL_XSTAMPS
+    c.tw[0] += tw1 - tw0; c.tw[1] += __builtin_amdgcn_s_memrealtime() - tw1; c.tw[4] += 1;
+#endif
+    return __builtin_amdgcn_readfirstlane((int)misc[1 + c.team]) != 0;   // (uniform over the team: every wave reads the same LDS word behind the barrier)
+}
+// done: the number of phases this member has now completed
+__device__ __forceinline__ void xarrive(XCtx& c, unsigned* flags, unsigned done) {
+#ifdef FQL_XSTAMPS
+    const unsigned long long ta0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every store of this phase has reached the L2 ...
+#ifdef FQL_XSTAMPS
+    const unsigned long long ta1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    xsync(c);
+#ifdef FQL_XSTAMPS
+    c.tw[2] += ta1 - ta0; c.tw[3] += __builtin_amdgcn_s_memrealtime() - ta1;
+#endif
+    if (c.tid == 0) stg(reinterpret_cast<float*>(flags) + c.member, __builtin_bit_cast(float, done));   // ... before this member counts as arrived
+}
+
+// ---- the Euler chain (agents/fql.py:155-171) on its own path: flow_steps x (layer 0, hidden layers 1 .. nh - 1 with the head folded into the
+// last).  Everything a phase needs but the activations is already on the CU - hidden kernels in LDS, the rank-16 update of layer 0 and the
+// head rows in registers - so a phase is: wait, issue the panel loads, MFMA, reduce, epilogue, arrive; no op descriptor to decode.
+template <int NT>
+__device__ __forceinline__ void xchain_layer(XCtx& c, const XcdArgs& a, int l, const float (&w4f)[4]) {
+    const int H = a.H, J = H >> 4, nh = a.chain_nl + 1;
+    const float* A = a.hc[(l - 1) & 1];
+    float* Co = a.hc[l & 1];
+    const f32x4* wl = c.wlds + (size_t)(l - 1) * J * 64;
+    const f32x4 bv = ldg4(a.chain_b[l - 1] + 16 * c.member + 4 * c.q);
+    for (int t0 = 0; t0 < c.RT; t0 += NT) {
+        const int rb0 = c.g * c.R + 16 * t0;
+        f32x4 av[NT][8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int j = c.wave + 4 * jj;
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                av[u][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (j < J) av[u][jj] = ldx4(A, xtoff(c, rb0 + 16 * u, j, J));
+            }
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int j = c.wave + 4 * jj;
+            const f32x4 wv = j < J ? wl[j * 64 + c.lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t], av[u][jj][t], acc[u], 0, 0, 0);
+        }
+        xsync(c);
+#pragma unroll
+        for (int u = 0; u < NT; ++u) c.red[(c.wave * 4 + u) * 64 + c.lane] = acc[u];
+        xsync(c);
+        if (c.wave < NT) {
+            f32x4 v = c.red[(0 * 4 + c.wave) * 64 + c.lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) v += c.red[(w * 4 + c.wave) * 64 + c.lane];
+            v += bv;
+            f32x4 g;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) g[t] = gelu_f(v[t]);
+            const int rb = rb0 + 16 * c.wave;
+            if (l < nh - 1) stg4(Co + xtoff(c, rb, c.member, J), g);
+            else {   // last hidden layer: this member's 16 columns times its 16 rows of the action head -> a partial of the velocity
+                f32x4 pv{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) pv = __builtin_amdgcn_mfma_f32_16x16x4f32(w4f[t], g[t], pv, 0, 0, 0);
+                if (4 * c.q < a.ad) stg4(a.vp + ((size_t)c.member * a.B + rb + c.r) * 16 + 4 * c.q, pv);
+            }
+        }
+    }
+}
+// p0: team 0's phase index of the first chain phase; returns true when a wait timed out
+__device__ __forceinline__ bool xchain_block(XCtx& c, const XcdArgs& a, int p0, unsigned* cnt, const unsigned* cnt_other, FQL_GAS unsigned* err,
+                                             unsigned* misc, const float (&w4f)[4]) {
+    const int H = a.H, J = H >> 4, nh = a.chain_nl + 1;
+    const bool active = 16 * c.member < H;
+    f32x4 w0f;   // rows od .. od + 15 of the first kernel (the action block, t, zero padding) for this member's 16 columns
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int k = a.od + 4 * c.q + t;
+        w0f[t] = (active && k < a.in_p) ? ldg(a.w0 + (size_t)k * H + 16 * c.member + c.r) : 0.f;
+    }
+    unsigned p = (unsigned)p0;
+    if (p0 > 0 && xwait(c, cnt, cnt_other, p, 0u, err, misc)) return true;   // C0 is complete
+    xchain_fold(c, a, 0);
+    for (int s = 0; s < a.fs; ++s) {
+        if (s > 0) {
+            if (xwait(c, cnt, cnt_other, p, 0u, err, misc)) return true;
+#ifdef FQL_XSTAMPS
+            if (c.tid == 0) a.stamps[(((size_t)blockIdx.x * 2) * a.stamp_stride + p) * 4] = __builtin_amdgcn_s_memrealtime();
+#endif
+            xchain_fold(c, a, s);
+        }
+        // layer 0: GELU(C0 + [a_s | t_s] W0[act rows, t row]); K = 16, so wave u finishes row tile u by itself
+        if (active)
+            for (int t0 = 0; t0 < c.RT; t0 += 4) {
+                const int t = t0 + c.wave;
+                if (t < c.RT) {
+                    const int rb = c.g * c.R + 16 * t;
+                    const f32x4 c0v = ldx4(a.c0, xtoff(c, rb, c.member, J));
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(c.alds + (16 * t + c.r) * 16 + 4 * c.q);
+                    f32x4 acc{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0f[tt], av[tt], acc, 0, 0, 0);
+                    acc += c0v;
+                    f32x4 g;
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) g[tt] = gelu_f(acc[tt]);
+                    stg4(a.hc[0] + xtoff(c, rb, c.member, J), g);
+                }
+            }
+#ifdef FQL_XSTAMPS
+#define XCS(k) do { if (c.tid == 0) a.stamps[(((size_t)blockIdx.x * 2) * a.stamp_stride + p) * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define XCS(k) do {} while (0)
+#endif
+        XCS(1);
+        xarrive(c, cnt, p + 1u); XCS(2); ++p;
+        for (int l = 1; l < nh; ++l) {
+            if (xwait(c, cnt, cnt_other, p, 0u, err, misc)) return true;
+            XCS(0);
+            if (active) {
+                if (c.RT & 1) xchain_layer<1>(c, a, l, w4f);
+                else xchain_layer<2>(c, a, l, w4f);
+            }
+            XCS(1);
+            xarrive(c, cnt, p + 1u); XCS(2); ++p;
+        }
+    }
+    return false;
+}
+
+// 512 threads: two teams of four waves.  Team 0 runs the critical path (C0, the Euler chain, the one-step actor's backward), team 1
+// everything else; each has its own phase list and its own per-XCD arrival counter, and a phase may also wait for a phase of the other
+// team.  On a SIMD one wave of each team is resident: while one waits for its loads or its barrier the other has the matrix pipe.
+__global__ __launch_bounds__(512, 2) void fql_xcd_kernel(const XcdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float xlds[];
     XCtx c;
-    c.lane = threadIdx.x & 63; c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    c.lane = threadIdx.x & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    c.team = wave8 >> 2; c.wave = wave8 & 3; c.tid = threadIdx.x & 255;
     c.r = c.lane & 15; c.q = c.lane >> 4;
-    c.R = a.R; c.RT = a.RT; c.st2 = nullptr;
+    c.R = a.R; c.RT = a.RT; c.st2 = nullptr; c.bt = 0u;
+    for (int i = 0; i < 6; ++i) c.tw[i] = 0;
+    c.stl = reinterpret_cast<unsigned long long*>(xlds + 2 * (16 * 64 * 4 + 512) + XCD_MAXROWS * 16 + 16 + a.chain_nl * (a.H >> 4) * 64 * 4) + 16 * c.team;
     c.g = (int)(__builtin_amdgcn_s_getreg(6164) & 7u);   // HW_REG_XCC_ID[3:0]: the XCD this workgroup runs on
-    c.red = reinterpret_cast<f32x4*>(xlds);                       // 16 x 64 float4
-    c.stat = xlds + 16 * 64 * 4;                                  // 4 x 4 x 16 x 2
-    c.alds = c.stat + 512;                                        // [R][16]
-    float* misc = c.alds + XCD_MAXROWS * 16;                      // 16 words
-    f32x4* wl = reinterpret_cast<f32x4*>(misc + 16);
+    float* tl = xlds + c.team * (16 * 64 * 4 + 512);              // per team: reduction slots, statistics
+    c.red = reinterpret_cast<f32x4*>(tl);                         // 16 x 64 float4
+    c.stat = tl + 16 * 64 * 4;                                    // 4 x 4 x 16 x 2
+    float* sh = xlds + 2 * (16 * 64 * 4 + 512);
+    c.alds = sh;                                                  // [R][16] (team 0)
+    unsigned* misc = reinterpret_cast<unsigned*>(sh + XCD_MAXROWS * 16);   // 16 words: ticket, time-out flags, team barrier words
+    f32x4* wl = reinterpret_cast<f32x4*>(sh + XCD_MAXROWS * 16 + 16);
     c.wlds = a.chain_nl > 0 ? wl : nullptr;
-    FQL_GAS unsigned* cnt = (FQL_GAS unsigned*)(a.sync + 32 * c.g);
+    c.bar = (__attribute__((address_space(3))) unsigned*)(misc + 4 + c.team);
+    unsigned* cnt = a.sync + 32 * (c.team ? 17 + c.g : c.g);                  // this team's arrival flags of this XCD: one word per member
+    const unsigned* cnt_other = a.sync + 32 * (c.team ? c.g : 17 + c.g);
     FQL_GAS unsigned* err = (FQL_GAS unsigned*)(a.sync + 32 * 16);
     if (threadIdx.x == 0) {
-        reinterpret_cast<unsigned*>(misc)[0] = __hip_atomic_fetch_add((FQL_GAS unsigned*)(a.sync + 32 * (8 + c.g)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        reinterpret_cast<unsigned*>(misc)[1] = 0u;   // "a wait of this workgroup timed out"
+        misc[0] = __hip_atomic_fetch_add((FQL_GAS unsigned*)(a.sync + 32 * (8 + c.g)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        misc[1] = 0u; misc[2] = 0u;   // "a wait of team 0 / 1 timed out"
+        misc[4] = 0u; misc[5] = 0u;   // team barrier words
+    }
+    {   // pull the op and phase tables into this XCD's L2 (they are read with scalar loads, one cold miss each otherwise)
+        const int nphase = a.nphase0 + a.nphase1;
+        const __attribute__((address_space(4))) int* l0 = (const __attribute__((address_space(4))) int*)(a.phases + (a.nphase0 - 1));
+        const __attribute__((address_space(4))) int* l1 = (const __attribute__((address_space(4))) int*)(a.phases + (nphase - 1));
+        const int nops = max(l0[0] + l0[1], l1[0] + l1[1]);
+        float acc = 0.f;
+        for (int i = threadIdx.x * 16; i < (int)(nops * sizeof(XOp) / 4); i += 512 * 16) acc += ldg(reinterpret_cast<const float*>(a.ops) + i);
+        for (int i = threadIdx.x * 16; i < (int)(nphase * sizeof(XPhase) / 4); i += 512 * 16) acc += ldg(reinterpret_cast<const float*>(a.phases) + i);
+        if (acc == 1.2345e-30f) misc[15] = 1u;   // (keeps the loads alive)
     }
     __syncthreads();
-    c.member = __builtin_amdgcn_readfirstlane((int)reinterpret_cast<unsigned*>(misc)[0]);   // (an LDS read: uniform, but only this tells the compiler)
+    c.member = __builtin_amdgcn_readfirstlane((int)misc[0]);   // (an LDS read: uniform, but only this tells the compiler)
     if (c.member >= XCD_NMEM) {   // more than 32 workgroups on this XCD: not a placement this kernel runs on
         if (threadIdx.x == 0) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -615,7 +833,7 @@ __global__ __launch_bounds__(256, 1) void fql_xcd_kernel(const XcdArgs a) {
     const int JH = a.H >> 4;
     if (c.wlds && 16 * c.member < a.H) {
         for (int l = 0; l < a.chain_nl; ++l)
-            for (int i = threadIdx.x; i < JH * 64; i += 256) {
+            for (int i = threadIdx.x; i < JH * 64; i += 512) {
                 const int j = i >> 6, ln = i & 63, rr = ln & 15, qq = ln >> 4;
                 f32x4 v;
                 const float* p = a.chain_w[l] + (size_t)(16 * j + 4 * qq) * a.H + 16 * c.member + rr;
@@ -631,52 +849,45 @@ __global__ __launch_bounds__(256, 1) void fql_xcd_kernel(const XcdArgs a) {
         const int k = 16 * c.member + 4 * c.q + t;
         w4f[t] = (a.w4 && k < a.H && c.r < a.ap) ? ldg(a.w4 + (size_t)k * a.ap + c.r) : 0.f;
     }
-    __syncthreads();
+    __syncthreads();   // (the last workgroup-wide barrier: from here on the two teams go their own ways)
+    const int np = c.team ? a.nphase1 : a.nphase0;
+    const XPhase* phs = a.phases + (c.team ? a.nphase0 : 0);
     bool dead = false;
-    for (int p = 0; p < a.nphase; ++p) {
-        if (p > 0) {
-            if (threadIdx.x == 0) {
-                const unsigned want = (unsigned)XCD_NMEM * (unsigned)p;
-                unsigned spins = 0;
-                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 22) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        reinterpret_cast<unsigned*>(misc)[1] = 1u;
-                        break;
-                    }
-                }
-            }
-            __syncthreads();
-            if (__builtin_amdgcn_readfirstlane((int)reinterpret_cast<unsigned*>(misc)[1])) dead = true;
-        }
-        if (dead) break;   // (uniform: every thread read the same LDS word behind the barrier)
-#ifdef FQL_XSTAMPS
-        unsigned long long* stp = a.stamps + ((size_t)blockIdx.x * a.nphase + p) * 4;
-        if (threadIdx.x == 0) stp[0] = __builtin_amdgcn_s_memrealtime();
-#endif
+    for (int p = 0; p < np; ++p) {
         XPhase ph;
-        ph.first = *(const __attribute__((address_space(4))) int*)&a.phases[p].first;
-        ph.count = *(const __attribute__((address_space(4))) int*)&a.phases[p].count;
+        {
+            const __attribute__((address_space(4))) int* src = (const __attribute__((address_space(4))) int*)(phs + p);
+            ph.first = src[0]; ph.count = src[1]; ph.wait_count = src[2]; ph.chain = src[3];
+        }
+        if (ph.chain > 0 && c.wlds && c.team != a.skip_team) {   // the Euler chain: `chain` phases on the dedicated path
+            if (xchain_block(c, a, p, cnt, cnt_other, err, misc, w4f)) break;
+            p += ph.chain - 1;
+            continue;
+        }
+        if (p > 0 || ph.wait_count > 0)
+            dead = xwait(c, cnt, cnt_other, (unsigned)p, (unsigned)ph.wait_count, err, misc);
+        if (dead) break;
 #ifdef FQL_XSTAMPS
-        c.st2 = (p == a.stamp_phase) ? a.stamps2 + (size_t)blockIdx.x * 16 : nullptr;
+        unsigned long long* stp = a.stamps + (((size_t)blockIdx.x * 2 + c.team) * a.stamp_stride + p) * 4;
+        if (c.tid == 0) stp[0] = __builtin_amdgcn_s_memrealtime();
+        c.st2 = (p == a.stamp_phase && c.team == a.stamp_team) ? a.stamps2 + (size_t)blockIdx.x * 16 : nullptr;
         XST(c, 8);
 #endif
+        if (c.team != a.skip_team)
         for (int oi = ph.first; oi < ph.first + ph.count; ++oi) xrun(c, a, a.ops + oi, w4f);
         XST(c, 7);
 #ifdef FQL_XSTAMPS
-        if (threadIdx.x == 0) stp[1] = __builtin_amdgcn_s_memrealtime();
+        if (c.tid == 0) stp[1] = __builtin_amdgcn_s_memrealtime();
+        if (c.st2 && c.tid == 0) for (int k = 0; k < 16; ++k) c.st2[k] = c.stl[k];
 #endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every store of this phase has reached the L2 ...
-        __syncthreads();
+        xarrive(c, cnt, (unsigned)p + 1u);
 #ifdef FQL_XSTAMPS
-        if (threadIdx.x == 0) stp[2] = __builtin_amdgcn_s_memrealtime();
-#endif
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before this member counts as arrived
-#ifdef FQL_XSTAMPS
-        if (threadIdx.x == 0) { stp[3] = __builtin_amdgcn_s_memrealtime(); a.stamps[((size_t)blockIdx.x * a.nphase) * 4 + 3] = (unsigned long long)((c.g << 8) | c.member); }
+        if (c.tid == 0) { stp[2] = __builtin_amdgcn_s_memrealtime(); stp[3] = __builtin_amdgcn_s_memtime(); if (p == 0) a.stamps2[256 * 16 + blockIdx.x] = (unsigned long long)((c.g << 8) | c.member); }
 #endif
     }
+#ifdef FQL_XSTAMPS
+    if (c.tid == 0 && c.team == 0) for (int i = 0; i < 5; ++i) a.stamps2[256 * 17 + blockIdx.x * 8 + i] = c.tw[i];
+#endif
 }
 
-#define FQL_XCD_LDS_FLOATS(chain_nl, H) (16 * 64 * 4 + 512 + XCD_MAXROWS * 16 + 16 + (chain_nl) * ((H) / 16) * 64 * 4)
+#define FQL_XCD_LDS_FLOATS(chain_nl, H) (2 * (16 * 64 * 4 + 512) + XCD_MAXROWS * 16 + 16 + (chain_nl) * ((H) / 16) * 64 * 4 + 64)
