@@ -1967,11 +1967,11 @@ struct fql_engine {
                 FQL_LAUNCH(fql_wfrag_kernel, dim3(wfrag_grid), dim3(FQL_THREADS), 0, s, (const WfragTask*)d_wfrag, wfrag_n, tl);
                 break;
             case OP_XCD:   // one workgroup per CU: 8 XCDs x 32 members
-                FQL_LAUNCH(fql_xcd_kernel, dim3(XCD_NGRP * XCD_NMEM), dim3(512), x_lds, s, L.op.xcd);
+                FQL_LAUNCH(fql_xcd_kernel, dim3(XCD_NGRP * XCD_NMEM), dim3(1024), x_lds, s, L.op.xcd);
                 break;
             case OP_ADAM: {
                 AdamArgs a{P, G, Mu, Nu, P + n_train, d_chunks, d_state, d_partials, L.op.adam_c0, (int)critic_size, cfg.lr, cfg.tau, tl,
-                           use_pec ? (const unsigned*)(pec_epoch + pec_teams) : (xsync ? (const unsigned*)(xsync + 16 * 32) : nullptr),
+                           use_pec ? (const unsigned*)(pec_epoch + pec_teams) : (xsync ? (const unsigned*)(xsync + 40 * 32) : nullptr),
                            L.op.adam_n1 > 0 ? L.op.adam_n : -1, L.op.adam_c1};
                 FQL_LAUNCH(fql_adam_kernel, dim3(L.op.adam_n < 0 ? n_chunks : L.op.adam_n + L.op.adam_n1), dim3(FQL_THREADS), 0, s, a);
                 break;
@@ -3098,25 +3098,51 @@ struct fql_engine {
             std::vector<XPhase> phases;
             double macs = 0.0;
             int nph[2] = {0, 0};
-            for (int team = 0; team < 2; ++team) {
+            const int nct = (B / 128 >= 2 && !getenv("FQL_XCD_ONE_CHAIN")) ? 2 : 1;   // two chain pipelines (even / odd row tiles) once an XCD holds two row tiles
+            int chain_p0 = 0, chain_len = 0;
+            for (int team = 0; team < 2; ++team) {   // group 0 = team 0 (critical path), group 1 = teams 2 and 3 (one shared phase list)
                 int maxlv = -1;
                 for (const XEmit& e : xe) if (e.chain == (team == 0)) maxlv = std::max(maxlv, e.level);
                 int waited = 0;   // (a team's phases run in order: a wait already made covers the later ones)
                 for (int lv = 0; lv <= maxlv; ++lv) {
-                    XPhase ph{(int)ops.size(), 0, 0, 0};
+                    XPhase ph{};
+                    ph.first = (int)ops.size();
+                    std::vector<const XEmit*> sel;
+                    int wt = 0;
                     for (const XEmit& e : xe)
-                        if (e.chain == (team == 0) && e.level == lv) { ops.push_back(e.op); ph.count++; ph.wait_count = std::max(ph.wait_count, e.wait); }
-                    if (ph.wait_count <= waited) ph.wait_count = 0; else waited = ph.wait_count;
-                    if (team == 0 && ph.count == 1 && ops[ph.first].kind == XK_CHAIN_L0 && ops[ph.first].step == 0) ph.chain = fs * nh;
+                        if (e.chain == (team == 0) && e.level == lv) { sel.push_back(&e); wt = std::max(wt, e.wait); }
+                    if (wt <= waited) wt = 0; else waited = wt;
+                    if (team == 0) {
+                        for (const XEmit* e : sel) ops.push_back(e->op);
+                        ph.count = ph.count_a = (int)sel.size();
+                        ph.wait[2] = ph.wait[3] = wt;   // the other group's phases are those of teams 2 and 3
+                        if (ph.count == 1 && sel[0]->op.kind == XK_CHAIN_L0 && sel[0]->op.step == 0) { ph.chain = fs * nh; chain_p0 = lv; chain_len = fs * nh; }
+                        // the first phase behind the chain needs the second pipeline's last step too
+                        if (nct == 2 && chain_len > 0 && lv == chain_p0 + chain_len) ph.wait[1] = chain_len;
+                    } else {
+                        // deal the ops of the phase to teams 2 and 3: heaviest first, each to the lighter team
+                        std::sort(sel.begin(), sel.end(), [](const XEmit* x, const XEmit* y) { return x->macs > y->macs; });
+                        std::vector<const XEmit*> ta, tb;
+                        double wa = 0.0, wb = 0.0;
+                        for (const XEmit* e : sel) {
+                            const double w = e->macs + 1e6;
+                            if (wa <= wb) { ta.push_back(e); wa += w; } else { tb.push_back(e); wb += w; }
+                        }
+                        for (const XEmit* e : ta) ops.push_back(e->op);
+                        for (const XEmit* e : tb) ops.push_back(e->op);
+                        ph.count = (int)sel.size(); ph.count_a = (int)ta.size();
+                        ph.wait[0] = wt;
+                    }
                     phases.push_back(ph);
                 }
                 nph[team] = maxlv + 1;
             }
             for (const XEmit& e : xe) macs += e.macs;
             if (getenv("FQL_DUMP")) {
-                fprintf(stderr, "[fql] xcd program: %zu ops, team 0: %d phases, team 1: %d phases\n", ops.size(), nph[0], nph[1]);
+                fprintf(stderr, "[fql] xcd program: %zu ops, team 0: %d phases, teams 2 / 3: %d phases, %d chain pipeline(s)\n", ops.size(), nph[0], nph[1], nct);
                 for (size_t pi = 0; pi < phases.size(); ++pi) {
-                    fprintf(stderr, "[fql]  team %d phase %2d (waits for %2d of the other):", pi < (size_t)nph[0] ? 0 : 1, (int)(pi < (size_t)nph[0] ? pi : pi - nph[0]), phases[pi].wait_count);
+                    fprintf(stderr, "[fql]  %s phase %2d (waits %d %d %d %d; %d ops to the first team):", pi < (size_t)nph[0] ? "team 0" : "teams 2/3", (int)(pi < (size_t)nph[0] ? pi : pi - nph[0]),
+                            phases[pi].wait[0], phases[pi].wait[1], phases[pi].wait[2], phases[pi].wait[3], phases[pi].count_a);
                     for (int i = phases[pi].first; i < phases[pi].first + phases[pi].count; ++i) fprintf(stderr, " k%d(%dx%d,f%x)", ops[i].kind, ops[i].K, ops[i].N, ops[i].flags);
                     fprintf(stderr, "\n");
                 }
@@ -3132,6 +3158,7 @@ struct fql_engine {
             a.ops = (const XOp*)up(ops.data(), ops.size() * sizeof(XOp));
             a.phases = (const XPhase*)up(phases.data(), phases.size() * sizeof(XPhase));
             a.nphase0 = nph[0]; a.nphase1 = nph[1];
+            a.nct = nct; a.chain_p0 = chain_p0;
             a.B = B; a.R = B / 8; a.RT = B / 128;
             a.sync = xsync; a.xpart = xpart;
             a.chain_nl = nh - 1; a.H = H;
@@ -3144,15 +3171,15 @@ struct fql_engine {
             a.lds_floats = FQL_XCD_LDS_FLOATS(a.chain_nl, H);
             a.skip_team = getenv("FQL_XCD_SKIP_TEAM") ? atoi(getenv("FQL_XCD_SKIP_TEAM")) : -1;
 #ifdef FQL_XSTAMPS
-            a.stamp_stride = std::max(nph[0], nph[1]);
-            a.stamps = (unsigned long long*)dalloc(ws_allocs, ((size_t)512 * a.stamp_stride * 4 + 256 * 25) * 2);
-            a.stamps2 = a.stamps + (size_t)512 * a.stamp_stride * 4;
+            a.stamp_stride = std::max(std::max(nph[0], nph[1]), chain_len + 1);
+            a.stamps = (unsigned long long*)dalloc(ws_allocs, ((size_t)1024 * a.stamp_stride * 4 + 256 * 25) * 2);
+            a.stamps2 = a.stamps + (size_t)1024 * a.stamp_stride * 4;
             a.stamp_phase = getenv("FQL_XSTAMP_PHASE") ? atoi(getenv("FQL_XSTAMP_PHASE")) : -1;
             a.stamp_team = getenv("FQL_XSTAMP_TEAM") ? atoi(getenv("FQL_XSTAMP_TEAM")) : 0;
             if (mode == 0) x_stamps = a.stamps;
 #endif
             x_lds = (size_t)a.lds_floats * sizeof(float);
-            x_nphase = std::max(nph[0], nph[1]); x_nops = (int)ops.size();
+            x_nphase = std::max(std::max(nph[0], nph[1]), chain_len + 1); x_nops = (int)ops.size();
             xo.reads = {X_os, X_bc, X_eu, X_c1, X_c2, X_ct, vel, w_rew, w_mask, w_act, X_e0};
             for (const XEmit& e : xe) for (const void* w : e.writes) xo.writes.push_back(w);
             xo.fin_mode = 0;
@@ -3308,13 +3335,13 @@ struct fql_engine {
         launches_per_update = prog_full.exec ? (int64_t)prog_full.launches.size()
                                              : (int64_t)prog_fwdbwd.launches.size() + (int64_t)prog_opt.launches.size();
         if (xcd_eligible()) {
-            xsync = (unsigned*)dalloc(W, 32 * 32); xpart = dalloc(W, 8 * 16); xvp = dalloc(W, (size_t)XCD_NMEM * B * 16);
+            xsync = (unsigned*)dalloc(W, 41 * 32); xpart = dalloc(W, 8 * 16); xvp = dalloc(W, (size_t)XCD_NMEM * B * 16);
             build_xcd_program(prog_xfull, 0);
             build_xcd_program(prog_xbegin, 1);
             build_xcd_program(prog_xopt, 2);
             HIP_CHECK(hipFuncSetAttribute((const void*)fql_xcd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x_lds));
             int per_cu = 0;   // every workgroup waits for its XCD's other 31: all 256 must be resident, one per CU
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fql_xcd_kernel, 512, x_lds) != hipSuccess || per_cu < 1) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fql_xcd_kernel, 1024, x_lds) != hipSuccess || per_cu < 1) {
                 (void)hipGetLastError();
             } else {
                 schedule(prog_xfull, W); schedule(prog_xbegin, W); schedule(prog_xopt, W);
@@ -4299,14 +4326,14 @@ extern "C" int fql_profile_update(fql_handle h, int batch_size, int cap, int* ty
 extern "C" int fql_debug_xcd_err(fql_handle h, unsigned* out) {
     if (!h || !h->xsync || !out) return FQL_E_NOTFOUND;
     if (hipDeviceSynchronize() != hipSuccess) return FQL_E_HIP;
-    return hipMemcpy(out, h->xsync + 16 * 32, 4, hipMemcpyDeviceToHost) == hipSuccess ? FQL_OK : FQL_E_HIP;
+    return hipMemcpy(out, h->xsync + 40 * 32, 4, hipMemcpyDeviceToHost) == hipSuccess ? FQL_OK : FQL_E_HIP;
 }
 
 // Diagnostic only (-DFQL_XSTAMPS builds): the phase stamps of the last XCD-resident launch, [256][phases][4] ticks of 10 ns
 extern "C" int fql_debug_xcd_stamps(fql_handle h, unsigned long long* out, size_t cap, int* nphase) {
     if (!h || !h->x_stamps) return FQL_E_NOTFOUND;
     if (nphase) *nphase = h->x_nphase;
-    const size_t n = (size_t)512 * h->x_nphase * 4 + 256 * 25;
+    const size_t n = (size_t)1024 * h->x_nphase * 4 + 256 * 25;
     if (cap < n) return FQL_E_INVALID;
     if (hipDeviceSynchronize() != hipSuccess) return FQL_E_HIP;
     return hipMemcpy(out, h->x_stamps, n * 8, hipMemcpyDeviceToHost) == hipSuccess ? FQL_OK : FQL_E_HIP;

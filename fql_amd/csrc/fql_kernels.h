@@ -1890,7 +1890,7 @@ struct PrepArgs {
     int tl;   // timeline id (diagnostics)
     int part; // 0: every output; 1: the critical lane's inputs only (X_eu, X_e0); 2: everything else (one launch per lane: neither lane
               //    then waits for the other at the start of the update)
-    unsigned* xsync;  // XCD-resident launch behind this one: its arrival counters and tickets (32-word slots 0..24 but the sticky error slot 16) are zeroed here (fql_xcd.h), or null
+    unsigned* xsync;  // XCD-resident launch behind this one: its arrival flags and tickets (32-word slots 0..39; slot 40 is the sticky error word) are zeroed here (fql_xcd.h), or null
 };
 
 // agents/fql.py:52-56 (x_t, vel), :144-150 (noise), utils/datasets.py:64-100 (index draw + gather),
@@ -1898,8 +1898,7 @@ struct PrepArgs {
 __global__ __launch_bounds__(FQL_THREADS) void fql_prep_kernel(PrepArgs P) {
     tl_enter(P.tl);
     if (P.xsync && blockIdx.x == 0)
-        for (int i = threadIdx.x; i < 25 * 32; i += FQL_THREADS)
-            if (i < 16 * 32 || i >= 17 * 32) P.xsync[i] = 0u;
+        for (int i = threadIdx.x; i < 40 * 32; i += FQL_THREADS) P.xsync[i] = 0u;   // (slot 40, the error word, stays)
     const SrcDesc& S = *P.src;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + wave;
