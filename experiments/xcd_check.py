@@ -21,9 +21,9 @@ cfg, ds, batch, noise = make_problem(od, ad, B, (H,) * 4, seed=3)
 
 def run(no_xcd):
     if no_xcd:
-        os.environ['FQL_NO_XCD_UPDATE'] = '1'
+        os.environ.pop('FQL_XCHAIN', None)
     else:
-        os.environ.pop('FQL_NO_XCD_UPDATE', None)
+        os.environ['FQL_XCHAIN'] = '1'
     a = fql_amd.FQLAgent.create(0, batch['observations'][:1], batch['actions'][:1], cfg)
     a.set_params(randomize_params(a.get_params(), 5))
     infos = []

@@ -14,7 +14,7 @@
 #include "fql_conv.h"
 #include "fql_chain.h"
 #include "fql_aux.h"
-#include "fql_xcd.h"
+#include "fql_xchain.h"
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -123,7 +123,7 @@ struct Leaf {
 // program = ordered ops with read/write sets -> levels -> launches
 // ------------------------------------------------------------------------------------------------
 enum OpType { OP_GEMM, OP_GEMM64, OP_WGRAD, OP_LNBWD, OP_PREP, OP_POSTOS, OP_EULER_FIN, OP_PEC, OP_LOSS_CRITIC, OP_LOSS_Q, OP_LOSS_BC,
-              OP_LOSS_ACTOR, OP_CONV_WPREP, OP_CONV, OP_CONV_U8, OP_POOL, OP_POOL_BWD, OP_CONV_WGRAD, OP_CONV_WRED, OP_ENC_DZ, OP_CHAIN, OP_WFRAG, OP_XCD, OP_ADAM,
+              OP_LOSS_ACTOR, OP_CONV_WPREP, OP_CONV, OP_CONV_U8, OP_POOL, OP_POOL_BWD, OP_CONV_WGRAD, OP_CONV_WRED, OP_ENC_DZ, OP_CHAIN, OP_WFRAG, OP_XCHAIN, OP_ADAM,
               OP_FINALIZE };
 
 struct Op {
@@ -147,7 +147,7 @@ struct Op {
     ConvWredArgs cwr;
     EncDzArgs edz;
     ChainArgs chain;
-    XcdArgs xcd;
+    XChainArgs xchain;
     const ConvWprepTask* wprep_tasks = nullptr;
     int wprep_n = 0;
     int cw_grid = 0;
@@ -346,15 +346,13 @@ struct fql_engine {
     };
     std::map<int, std::unique_ptr<Eval>> evals;
 
-    // XCD-resident update (fql_xcd.h): prep -> one persistent launch (all forward and input-gradient passes) -> weight gradients ->
-    // Adam -> finalize.  State agents, fp32, every hidden layer of a net equally wide (multiple of 16, <= 512), batch = 128 k.
-    bool xcd_ok = false;
-    unsigned* xsync = nullptr;      // [17][32] words: arrival counters, tickets (zeroed by the prep launch), sticky error word
-    float *xpart = nullptr, *xvp = nullptr;
-    Program prog_xfull, prog_xbegin, prog_xopt;
-    int x_nphase = 0, x_nops = 0;
+    // XCD-resident Euler chain (fql_xchain.h): the whole chain as one persistent launch on the critical lane
+    bool use_xchain = false;
+    unsigned* xsync = nullptr;      // [17][32] words: arrival flags, tickets (zeroed by the prep launch), sticky error word
+    float* xvp = nullptr;           // head partials [32][B][16]
     size_t x_lds = 0;
-    bool wfrag_dirty = false;       // the launch-per-level programs read fragment-major copies of the BC flow's kernels: refresh before using them again
+    bool x_wlds = false;            // the chain's hidden kernels resident in LDS (else streamed into registers behind each arrival)
+    unsigned long long* x_stamps = nullptr;
 
     int64_t launches_per_update = 0;
     // lazily read infos (the reference returns device scalars that are only read at log time, main.py:276): a ring of pinned host
@@ -1220,8 +1218,49 @@ struct fql_engine {
         op.writes = {tgt};
         push(pr, op);
     }
+    // The whole chain as ONE persistent XCD-resident launch (fql_xchain.h): 8 row blocks x 32 column slices, activations exchanged through
+    // each XCD's own L2, hidden kernels resident in LDS.
+    bool xchain_eligible() const {
+        // opt-in (FQL_XCHAIN=1).  Measured at B = 256, H = 512: the chain alone 136 us in this ONE launch against ~170 us as 30 launches, but the update
+        // 383 us against 352 us: the persistent workgroup holds 115 KB of every CU's LDS for the hidden kernels, the side lanes' workgroups beside it
+        // drop from three or four per CU to one, and they end the update (profiles/r03_xcd_resident.txt).
+        if (!getenv("FQL_XCHAIN") || atoi(getenv("FQL_XCHAIN")) == 0) return false;
+        if (visual || cfg.precision != 0 || cfg.actor_layer_norm || cfg.act_dim > 15) return false;
+        if (num_cus != XCH_NGRP * XCH_NMEM || B % 128 != 0 || B / 128 > XCH_MAXRT) return false;
+        const Net& n = nets[NET_BC];
+        const int nh = n.nl() - 1;
+        if (nh < 2 || nh - 1 > 7) return false;
+        const int H = n.layers[0].out;
+        if (H % 16 || H > 512 || n.layers[0].in_p > 128 || n.layers[nh].out_p != 16) return false;
+        for (int l = 0; l < nh; ++l) if (n.layers[l].out != H || n.layers[l].out_p != H) return false;
+        // beside this kernel's workgroup a CU must still take a side-lane workgroup: <= 116 KB of its 160 KB of LDS
+        if ((size_t)FQL_XCHAIN_LDS_FLOATS(nh - 1, H, true) * sizeof(float) > 116 * 1024) return false;
+        return true;
+    }
+    void emit_euler_xcd(Program& pr) {
+        const Net& n = nets[NET_BC];
+        const int nh = n.nl() - 1;
+        Op op{};
+        op.type = OP_XCHAIN;
+        XChainArgs& a = op.xchain;
+        a.B = B; a.R = B / 8; a.RT = B / 128;
+        a.H = n.layers[0].out_p; a.nl = nh - 1;
+        a.od = cfg.obs_dim; a.ad = cfg.act_dim; a.ap = pad16(cfg.act_dim); a.in_p = n.in_p(); a.fs = cfg.flow_steps;
+        a.x_e0 = X_eu; a.x_eu = X_eu;   // (C0 masks the action / t rows of the first kernel: the Euler input serves as its observation-only input too)
+        a.w0 = P + n.layers[0].w; a.b0 = P + n.layers[0].b;
+        for (int l = 1; l < nh; ++l) { a.w[l - 1] = P + n.layers[l].w; a.b[l - 1] = P + n.layers[l].b; }
+        a.w4 = P + n.layers[nh].w; a.b4 = P + n.layers[nh].b;
+        a.hc[0] = p_eu.g[0]; a.hc[1] = p_eu.g[1];
+        a.vp = xvp; a.tgt = tgt; a.sync = xsync;
+        a.stamps = x_stamps;
+        op.reads = {X_eu};
+        for (const Layer& L : n.layers) op.reads.push_back(P + L.w);
+        op.writes = {tgt, xvp, p_eu.g[0], p_eu.g[1]};
+        push(pr, op);
+    }
     // refresh of the fragment-major copies inside a program, behind the Adam launch that rewrites the BC flow's kernels
     void emit_wfrag(Program& pr) {
+        if (use_xchain) return;   // (nothing reads the copies: the persistent chain takes the kernels as flax stores them)
         if (!use_chain) return;
         const Net& n = nets[NET_BC];
         Op op{};
@@ -1493,6 +1532,7 @@ struct fql_engine {
                         const int ncu = std::max(1, num_cus);
                         const double m64 = 2.0 * ((t64 + ncu - 1) / ncu) + other / ncu, m32 = 1.0 * ((2 * t64 + ncu - 1) / ncu) + other / ncu;
                         if (t64 > 0 && m32 < m64 && !wide_tiles) nj = 1;
+                        if (use_xchain && x_wlds) nj = 1;   // 36 KB of LDS: fits beside the persistent chain's workgroup (115 KB) on a CU, 32 x 64 tiles (53 KB) do not
                         if (nj_env == 1 || nj_env == 2) nj = nj_env;
                     }
                     for (const Op* o : sel) {
@@ -1535,7 +1575,7 @@ struct fql_engine {
                     int tilel = 0;
                     for (const Op* o : sell) {
                         LnBwdTask t = o->ln;
-                        t.ntiles_rows = t.cols_only ? 0 : (t.M + 3) / 4; t.tile0 = tilel;
+                        t.ntiles_rows = (t.M + 3) / 4; t.tile0 = tilel;
                         tilel += t.ntiles_rows + (t.dgamma ? t.H / 16 : 0);
                         tl.push_back(t);
                     }
@@ -1714,7 +1754,7 @@ struct fql_engine {
                     std::vector<LnBwdTask> tb;
                     for (const Op* o : sel) {
                         LnBwdTask t = o->ln;
-                        t.ntiles_rows = t.cols_only ? 0 : (t.M + 3) / 4;
+                        t.ntiles_rows = (t.M + 3) / 4;
                         t.tile0 = tile;
                         tile += t.ntiles_rows + (t.dgamma ? t.H / 16 : 0);
                         tb.push_back(t);
@@ -1763,7 +1803,11 @@ struct fql_engine {
                 m = (double)o.chain.M * H * H + (o.chain.variant == 0 ? (double)o.chain.M * 16.0 * H : 0.0) + (o.chain.variant == 2 ? (double)o.chain.M * H * o.chain.ap : 0.0);
                 if (o.chain.variant == 4) m = (double)o.chain.M * o.chain.hw * o.chain.ncol;
             }
-            else if (o.type == OP_XCD) m = xcd_macs;
+            else if (o.type == OP_XCHAIN) {
+                const Net& nb = nets[NET_BC];
+                for (const Layer& L : nb.layers) m += (double)B * L.in * L.out;
+                m = m * cfg.flow_steps - (double)B * cfg.obs_dim * nb.layers[0].out * (cfg.flow_steps - 1);   // (the obs part of layer 0 is computed once)
+            }
             else if (o.type == OP_CONV || o.type == OP_CONV_U8) m = (double)o.conv.N * o.conv.H * o.conv.W * 9.0 * (o.conv.transposed ? o.conv.Ci : o.conv.Ci_real) * o.conv.Co;
             else if (o.type == OP_CONV_WGRAD) m = (double)o.cw.N * o.cw.H * o.cw.W * 9.0 * o.cw.Ci_real * o.cw.Co;
             pr.launches[li].macs += m;
@@ -1966,20 +2010,20 @@ struct fql_engine {
             case OP_WFRAG:
                 FQL_LAUNCH(fql_wfrag_kernel, dim3(wfrag_grid), dim3(FQL_THREADS), 0, s, (const WfragTask*)d_wfrag, wfrag_n, tl);
                 break;
-            case OP_XCD:   // one workgroup per CU: 8 XCDs x 32 members
-                FQL_LAUNCH(fql_xcd_kernel, dim3(XCD_NGRP * XCD_NMEM), dim3(1024), x_lds, s, L.op.xcd);
+            case OP_XCHAIN:   // one workgroup per CU: 8 XCDs x 32 members
+                if (x_wlds) FQL_LAUNCH(fql_xchain_kernel<true>, dim3(XCH_NGRP * XCH_NMEM), dim3(256), x_lds, s, L.op.xchain);
+                else FQL_LAUNCH(fql_xchain_kernel<false>, dim3(XCH_NGRP * XCH_NMEM), dim3(256), x_lds, s, L.op.xchain);
                 break;
             case OP_ADAM: {
                 AdamArgs a{P, G, Mu, Nu, P + n_train, d_chunks, d_state, d_partials, L.op.adam_c0, (int)critic_size, cfg.lr, cfg.tau, tl,
-                           use_pec ? (const unsigned*)(pec_epoch + pec_teams) : (xsync ? (const unsigned*)(xsync + 40 * 32) : nullptr),
+                           use_pec ? (const unsigned*)(pec_epoch + pec_teams) : (xsync ? (const unsigned*)(xsync + 16 * 32) : nullptr),
                            L.op.adam_n1 > 0 ? L.op.adam_n : -1, L.op.adam_c1};
                 FQL_LAUNCH(fql_adam_kernel, dim3(L.op.adam_n < 0 ? n_chunks : L.op.adam_n + L.op.adam_n1), dim3(FQL_THREADS), 0, s, a);
                 break;
             }
             case OP_FINALIZE:
                 FQL_LAUNCH(fql_finalize_kernel, dim3(1), dim3(FQL_THREADS), 0, s,
-                                   FinalizeArgs{d_state, d_chunks, d_partials, d_leaf_range, n_chunks, n_train_leaves, L.op.fin_mode, tl,
-                                                L.op.fin_mode == 3 ? xpart : nullptr, B, cfg.act_dim, cfg.alpha});
+                                   FinalizeArgs{d_state, d_chunks, d_partials, d_leaf_range, n_chunks, n_train_leaves, L.op.fin_mode, tl});
                 break;
         }
     }
@@ -2369,7 +2413,7 @@ struct fql_engine {
             op.type = OP_PREP;
             op.prep = PrepArgs{d_src, st, seed, B, od, ad, inp_c, inp_b, ap, X_os, X_bc, X_eu, X_c1, X_c2, X_ct, vel, w_rew, w_mask, w_act,
                                fused_euler ? X_e0 : nullptr, nullptr, nullptr, nullptr, nullptr};
-            op.prep.tl = -1; op.prep.part = 0;
+            op.prep.tl = -1; op.prep.part = 0; op.prep.xsync = use_xchain ? xsync : nullptr;
             // One batch-assembly launch per lane (state agents): the side lane then has no dependency on the critical lane at the
             // start of the update.  (On this runtime a graph branch whose first node waits for a node of the other branch starts
             // only ~16 launches of that branch later: profiles/r02_timeline_concurrent.txt.)
@@ -2403,7 +2447,7 @@ struct fql_engine {
         const bool lanes3 = lanes3_env && !visual && !split_build;
         const int fill_lane = lanes3 ? 2 : 1;
         if (!split_build) fill_lane_full = fill_lane;
-        wide_tiles = lanes3;
+        wide_tiles = lanes3 && !(use_xchain && x_wlds);   // (beside the persistent chain's workgroup a CU has ~45 KB of LDS left: 32 x 32 side tiles fit, 32 x 64 do not)
         place("os", 1, true);
         // one-step actor on [next_obs|eps1 ; obs|z ; obs|eps2]  (agents/fql.py:25,65,82)
         emit_forward(pr, p_os, with_grads, GF_OS_SCATTER, X_ct, X_c2);
@@ -2510,9 +2554,10 @@ struct fql_engine {
         // critical lane).  Built, parity-green (bit-identical target) and measured no faster - bf16x3 3037 -> 3018, fp32 2555 -> 2550 updates/s: the 16
         // partial loads per element lengthen the prologue of all 256 workgroups by what the launch boundary saved - so it is opt-in.
         static const bool fuse_ef_env = getenv("FQL_FUSE_EF") != nullptr && atoi(getenv("FQL_FUSE_EF")) != 0;
-        euler_finish_fused = fuse_ef_env && with_grads && getenv("FQL_NO_FUSE_LA") == nullptr && !cfg.actor_layer_norm && !use_pec && fused_euler && use_chain &&
+        euler_finish_fused = fuse_ef_env && with_grads && getenv("FQL_NO_FUSE_LA") == nullptr && !cfg.actor_layer_norm && !use_pec && !use_xchain && fused_euler && use_chain &&
                              fs > 1 && vp_tiles <= 32;
-        if (use_pec) emit_euler_persistent(pr);
+        if (use_xchain) emit_euler_xcd(pr);
+        else if (use_pec) emit_euler_persistent(pr);
         else if (fused_euler && use_chain) emit_euler_chain(pr);
         else if (fused_euler) emit_euler_fused(pr);
         else
@@ -2765,455 +2810,11 @@ struct fql_engine {
         free_program(prog_loss);
         free_program(prog_split);
         free_program(prog_full);
-        free_program(prog_xfull); free_program(prog_xbegin); free_program(prog_xopt);
-        xcd_ok = false; xsync = nullptr; xpart = nullptr; xvp = nullptr;
+        use_xchain = false; xsync = nullptr; xvp = nullptr; x_stamps = nullptr;
         free_split();
         for (void* p : ws_allocs) hipFree(p);
         ws_allocs.clear();
     }
-
-    // ---------------------------------------------------------------------------------------
-    // XCD-resident update program (fql_xcd.h)
-    // ---------------------------------------------------------------------------------------
-    struct XEmit {
-        XOp op{};
-        std::vector<const void*> reads, writes;
-        int level = 0;
-        bool chain = false;   // team 0: the critical path (C0, Euler chain, one-step actor's backward); everything else is team 1's
-        int wait = 0;         // phases of the OTHER team that must be complete first
-        double macs = 0.0;
-    };
-    bool xcd_eligible() const {
-        if (getenv("FQL_NO_XCD_UPDATE")) return false;
-        if (visual || cfg.precision != 0 || cfg.normalize_q_loss || cfg.actor_layer_norm || !cfg.layer_norm) return false;
-        if (num_cus != 256 || B % 128 != 0 || B / 8 > XCD_MAXROWS) return false;
-        if (!fused_euler || cfg.act_dim > 15) return false;
-        for (int ni = 0; ni < NUM_NETS; ++ni) {
-            const Net& n = nets[ni];
-            const int nh = n.nl() - 1;
-            if (nh < 2) return false;
-            const int H = n.layers[0].out;
-            if (H % 16 || H > 512) return false;
-            for (int l = 0; l < nh; ++l) if (n.layers[l].out != H || n.layers[l].out_p != H) return false;
-            if (n.layers[0].in_p > 128 || n.layers[nh].out_p != 16) return false;
-        }
-        const Net& nb = nets[NET_BC];
-        if (nb.nl() - 2 > 7) return false;
-        return true;
-    }
-    // tile-major twin of a [rows, H] workspace buffer (fql_xcd.h, Layout), allocated on first use
-    std::map<const float*, std::pair<float*, size_t>> x_twins;
-    float* xT(float* p, size_t nfloats) {
-        auto it = x_twins.find(p);
-        if (it != x_twins.end() && it->second.second >= nfloats) return it->second.first;
-        float* t = dalloc(ws_allocs, nfloats);
-        x_twins[p] = {t, nfloats};
-        return t;
-    }
-    // rowmajor: 0 = no row-major copy of the GELU outputs, 1 = keep one (read by the weight-gradient launch)
-    void x_forward(std::vector<XEmit>& xe, const PassBuf& p, int nblk, bool save, int head_flags, int member0, bool rowmajor, float* sc0 = nullptr, float* sc1 = nullptr) {
-        const Net& n = nets[p.net];
-        const int L = n.nl() - 1;
-        for (int l = 0; l <= L; ++l) {
-            const Layer& ly = n.layers[l];
-            XEmit e;
-            XOp& o = e.op;
-            o.kind = l < L ? XK_FWD : XK_HEAD;
-            const size_t rowsz = (size_t)nblk * B;
-            o.A = l == 0 ? p.x0 : xT(p.g[l - 1], rowsz * ly.in_p); o.lda = ly.in_p; o.K = ly.in_p;
-            if (l > 0) o.flags |= XF_A_TILE;
-            o.W = P + ly.w; o.ldw = ly.out_p; o.N = ly.out_p; o.bias = P + ly.b;
-            o.flags |= XF_BIAS;
-            o.nblk = nblk; o.blk_stride = B; o.member0 = l < L ? 0 : member0;
-            e.reads = {o.A};
-            if (l > 0 && n.layers[l - 1].ln) {
-                o.flags |= XF_LN;
-                o.ln_g = P + n.layers[l - 1].g; o.ln_b = P + n.layers[l - 1].be;
-                if (save) {
-                    o.flags |= XF_LN_STORE;
-                    o.ln_xout = p.xn[l - 1]; o.ln_stats = p.stats[l - 1];
-                    e.writes.push_back(o.ln_xout); e.writes.push_back(o.ln_stats);
-                }
-            }
-            if (l < L) {
-                o.Ct = xT(p.g[l], rowsz * ly.out_p); o.ldc = ly.out_p;
-                o.C = rowmajor ? p.g[l] : nullptr;
-                e.writes.push_back(o.Ct);
-                o.flags |= XF_GELU;
-                if (save) { o.flags |= XF_SAVEZ; o.Zout = xT(p.z[l], rowsz * ly.out_p); e.writes.push_back(o.Zout); }
-            } else {
-                o.C = p.out; o.ldc = ly.out_p;
-                o.flags |= head_flags;
-                if (head_flags & XF_OS_SCATTER) {
-                    o.o0 = sc0; o.o1 = sc1; o.i0 = nets[NET_C0].in_p(); o.i1 = cfg.obs_dim;
-                    e.writes.push_back(sc0); e.writes.push_back(sc1);
-                }
-            }
-            if (o.C) e.writes.push_back(o.C);
-            e.macs = (double)nblk * B * ly.in * ly.out;
-            xe.push_back(e);
-        }
-    }
-    // input-gradient chain of a pass (the weight gradients run in the launch behind).  seed: 0 = dz of the head is in memory (constant dQ),
-    // 1 = critic loss (dq built in the head's LayerNorm backward), 2 = BC flow loss, 3 = actor loss (one-step actor; row_off = B)
-    // param: the pass has parameter gradients (the weight-gradient launch reads dZ / dY row-major)
-    void x_backward(std::vector<XEmit>& xe, const PassBuf& p, int row_off, bool input_grad, int seed, int member0, bool param) {
-        const Net& n = nets[p.net];
-        const int L = n.nl() - 1;
-        const int ad = cfg.act_dim, ap = pad16(ad);
-        const size_t fwd_rows = (size_t)(row_off ? 3 : 1) * B;   // rows of the forward buffers (the one-step actor's hold three blocks)
-        auto rows = [&](float* base, int ld) { return base + (size_t)row_off * ld; };
-        for (int l = L; l >= 0; --l) {
-            const Layer& ly = n.layers[l];
-            if (l == 0 && !input_grad) break;
-            if (l == L && n.layers[l - 1].ln) {   // scalar head behind a LayerNorm: rank-1 dY inside the LayerNorm backward
-                const Layer& prev = n.layers[l - 1];
-                XEmit e;
-                XOp& o = e.op;
-                o.kind = XK_LNBWD; o.flags = XF_SYN | (seed == 1 ? XF_SEED_CRITIC : 0);
-                o.W = P + ly.w; o.ldw = ly.out_p;
-                o.p1 = xT(p.g[l - 1], fwd_rows * prev.out_p); o.Zmul = xT(p.z[l - 1], fwd_rows * prev.out_p); o.ln_stats = p.stats[l - 1]; o.ln_g = P + prev.g;
-                o.Ct = xT(p.dz[l - 1], (size_t)B * prev.out_p); o.C = param ? p.dz[l - 1] : nullptr; o.N = prev.out_p; o.ldc = prev.out_p;
-                o.nblk = 1; o.blk_stride = B; o.member0 = member0;
-                o.i0 = ly.out_p;
-                e.reads = {o.p1, o.Zmul, p.stats[l - 1]};
-                if (seed == 1) {
-                    const int e2 = p.net - NET_C0;
-                    o.p0 = p.out; o.p2 = p_ct[0].out; o.p3 = p_ct[1].out; o.p4 = w_rew; o.p5 = w_mask; o.o0 = p.dz[L];
-                    o.f0 = cfg.discount; o.i1 = cfg.q_agg; o.f1 = 1.0f / (float)B;
-                    (void)e2;
-                    e.reads.push_back(p.out); e.reads.push_back(p_ct[0].out); e.reads.push_back(p_ct[1].out);
-                    e.writes.push_back(p.dz[L]);
-                } else {
-                    o.p0 = p.dz[L];
-                }
-                e.writes.push_back(o.Ct);
-                if (o.C) e.writes.push_back(o.C);
-                xe.push_back(e);
-                continue;
-            }
-            XEmit e;
-            XOp& o = e.op;
-            o.nblk = 1; o.blk_stride = B; o.member0 = 0;
-            o.W = P + ly.w; o.ldw = ly.out_p;
-            o.N = ly.in_p; o.ldc = ly.in_p;
-            if (l == L) {   // actor head: the loss gradient is the A operand
-                o.kind = XK_SEED_DGRAD; o.K = 16;
-                o.flags = seed == 3 ? XF_SEED_ACTOR : 0;
-                o.o0 = p.dz[L];
-                if (seed == 3) {
-                    o.p0 = p_os.out + (size_t)B * ap; o.p2 = p_c2[0].dx0; o.p3 = p_c2[1].dx0; o.i0 = nets[NET_C0].in_p(); o.i1 = cfg.obs_dim;
-                    o.f0 = cfg.alpha * 2.0f / (float)(B * ad); o.o1 = tgt;
-                    e.reads = {p_os.out, p_c2[0].dx0, p_c2[1].dx0, xvp};
-                    e.writes.push_back(tgt);
-                    e.chain = true;
-                } else {
-                    o.p0 = p.out; o.p1 = vel; o.f0 = 2.0f / (float)(B * ad);
-                    e.reads = {p.out};
-                }
-                e.writes.push_back(p.dz[L]);
-            } else {
-                o.kind = XK_DGRAD; o.K = ly.out_p;
-                o.A = xT(p.dz[l], (size_t)B * ly.out_p); o.lda = ly.out_p; o.flags |= XF_A_TILE;
-                e.reads = {o.A};
-            }
-            if (l == 0) {
-                o.C = p.dx0;
-            } else if (n.layers[l - 1].ln) {
-                o.Ct = xT(p.dy[l - 1], (size_t)B * ly.in_p);
-                o.C = param ? p.dy[l - 1] : nullptr;
-            } else {
-                o.Ct = xT(p.dz[l - 1], (size_t)B * ly.in_p);
-                o.C = param ? p.dz[l - 1] : nullptr;
-                float* zt = xT(p.z[l - 1], fwd_rows * n.layers[l - 1].out_p);
-                o.flags |= XF_ZMUL; o.Zmul = rows(zt, n.layers[l - 1].out_p);
-                e.reads.push_back(zt);
-            }
-            if (o.Ct) e.writes.push_back(o.Ct);
-            if (o.C) e.writes.push_back(o.C);
-            e.macs = (double)B * ly.in * ly.out;
-            xe.push_back(e);
-            if (l > 0 && n.layers[l - 1].ln) {
-                const Layer& prev = n.layers[l - 1];
-                XEmit f;
-                XOp& q = f.op;
-                q.kind = XK_LNBWD; q.flags = 0;
-                q.A = xT(p.dy[l - 1], (size_t)B * prev.out_p); q.p1 = xT(p.g[l - 1], fwd_rows * prev.out_p); q.Zmul = xT(p.z[l - 1], fwd_rows * prev.out_p);
-                q.ln_stats = p.stats[l - 1]; q.ln_g = P + prev.g;
-                q.Ct = xT(p.dz[l - 1], (size_t)B * prev.out_p); q.C = param ? p.dz[l - 1] : nullptr; q.N = prev.out_p; q.ldc = prev.out_p;
-                q.nblk = 1; q.blk_stride = B; q.member0 = member0;
-                f.reads = {q.A, q.p1, q.Zmul, p.stats[l - 1]};
-                f.writes = {q.Ct};
-                if (q.C) f.writes.push_back(q.C);
-                xe.push_back(f);
-            }
-        }
-    }
-    // weight gradients of a pass as ops of the launch-per-level program behind the persistent launch (same kernels as emit_backward)
-    void x_wgrads(Program& pr, const PassBuf& p, int row_off, int M) {
-        const Net& n = nets[p.net];
-        const int L = n.nl() - 1;
-        auto rows = [&](float* base, int ld) { return base + (size_t)row_off * ld; };
-        for (int l = L; l >= 0; --l) {
-            const Layer& ly = n.layers[l];
-            Op op{};
-            op.type = OP_WGRAD;
-            WgradTask& w = op.wgrad;
-            w.X = (l == 0) ? rows(p.x0, ly.in_p) : rows(p.xn[l - 1], ly.in_p); w.ldx = ly.in_p;
-            w.dZ = p.dz[l]; w.ldz = ly.out_p;
-            w.dW = G + ly.w; w.ldw = ly.out_p; w.db = G + ly.b;
-            w.M = M; w.Kin = ly.in_p; w.N = ly.out_p;
-            op.reads = {(l == 0) ? (const void*)p.x0 : (const void*)p.xn[l - 1], p.dz[l]};
-            op.writes = {w.dW, w.db};
-            push(pr, op);
-            if (l > 0 && n.layers[l - 1].ln) {
-                const Layer& prev = n.layers[l - 1];
-                Op lo{};
-                lo.type = OP_LNBWD;
-                LnBwdTask& q = lo.ln;
-                q.cols_only = 1;
-                if (l == L) { q.dY = nullptr; q.dq = p.dz[L]; q.ldq = ly.out_p; q.wq = P + ly.w; q.ldw = ly.out_p; }
-                else q.dY = p.dy[l - 1];
-                q.Z = p.z[l - 1]; q.Gv = p.g[l - 1]; q.stats = p.stats[l - 1]; q.gamma = P + prev.g;
-                q.dZ = p.dz[l - 1];
-                q.dgamma = G + prev.g; q.dbeta = G + prev.be;
-                q.M = M; q.H = prev.out_p; q.ld = prev.out_p; q.width = prev.out;
-                lo.reads = {l == L ? (const void*)p.dz[L] : (const void*)p.dy[l - 1], p.g[l - 1], p.stats[l - 1]};
-                lo.writes = {q.dgamma, q.dbeta};
-                push(pr, lo);
-            }
-        }
-    }
-    void build_xcd_program(Program& pr, int mode) {   // mode 0: whole update, 1: forward + backward (data-parallel begin), 2: optimizer half
-        const int od = cfg.obs_dim, ad = cfg.act_dim, ap = pad16(ad);
-        const int inp_c = nets[NET_OS].in_p(), inp_b = nets[NET_BC].in_p();
-        DevState* st = d_state;
-        emit_lane = 0;
-        if (mode != 2) {
-            {
-                Op op{};
-                op.type = OP_PREP;
-                op.prep = PrepArgs{d_src, st, seed, B, od, ad, inp_c, inp_b, ap, X_os, X_bc, X_eu, X_c1, X_c2, X_ct, vel, w_rew, w_mask, w_act, X_e0,
-                                   nullptr, nullptr, nullptr, nullptr};
-                op.prep.tl = -1; op.prep.part = 0; op.prep.xsync = xsync;
-                op.writes = {X_os, X_bc, X_eu, X_c1, X_c2, X_ct, vel, w_rew, w_mask, w_act, X_e0};
-                push(pr, op);
-            }
-            std::vector<XEmit> xe;
-            const Net& nb = nets[NET_BC];
-            const int nh = nb.nl() - 1, H = nb.layers[0].out_p, fs = cfg.flow_steps;
-            float* Hc[2] = {p_eu.g[0], p_eu.g[1]};   // (used tile-major here: nothing outside the launch reads them)
-            {   // C0 = obs W0[obs rows] + b0: the loop-invariant part of the velocity field's first layer (agents/fql.py:166-169)
-                XEmit e;
-                XOp& o = e.op;
-                o.kind = XK_FWD; o.flags = XF_BIAS;
-                o.A = X_e0; o.lda = inp_b; o.K = inp_b; o.W = P + nb.layers[0].w; o.ldw = H; o.N = H; o.bias = P + nb.layers[0].b;
-                o.Ct = C0; o.ldc = H; o.nblk = 1; o.blk_stride = B;
-                e.reads = {X_e0}; e.writes = {C0}; e.chain = true;
-                e.macs = (double)B * od * H;
-                xe.push_back(e);
-            }
-            // the Euler chain first: it is the critical path, its ops lead their phases
-            for (int s = 0; s < fs; ++s) {
-                {
-                    XEmit e;
-                    XOp& o = e.op;
-                    o.kind = XK_CHAIN_L0; o.step = s;
-                    o.A = C0; o.Ct = Hc[0]; o.N = H; o.ldw = H; o.ldc = H; o.K = 16; o.nblk = 1; o.blk_stride = B;
-                    e.reads = {C0, X_eu}; if (s > 0) e.reads.push_back(xvp);
-                    e.writes = {Hc[0]}; e.chain = true;
-                    e.macs = (double)B * (ad + 1) * H;
-                    xe.push_back(e);
-                }
-                for (int l = 1; l < nh; ++l) {
-                    XEmit e;
-                    XOp& o = e.op;
-                    o.kind = l == nh - 1 ? XK_CHAIN_LAST : XK_CHAIN_MID;
-                    o.A = Hc[(l - 1) & 1]; o.lda = H; o.K = H; o.N = H; o.ldc = H; o.Ct = Hc[l & 1]; o.flags = XF_A_TILE;
-                    o.W = P + nb.layers[l].w; o.ldw = H; o.bias = P + nb.layers[l].b; o.i0 = l - 1; o.nblk = 1; o.blk_stride = B;
-                    e.reads = {o.A};
-                    e.writes = {l == nh - 1 ? (const void*)xvp : (const void*)o.Ct};
-                    e.chain = true;
-                    e.macs = (double)B * H * H + (l == nh - 1 ? (double)B * H * ad : 0.0);
-                    xe.push_back(e);
-                }
-            }
-            // one-step actor on [next_obs | eps1 ; obs | z ; obs | eps2]  (agents/fql.py:25,65,82); its head scatters clip(.) into the critic inputs
-            x_twins.clear();
-            x_forward(xe, p_os, 3, true, XF_OS_SCATTER, 0, true, X_ct, X_c2);
-            for (int e = 0; e < 2; ++e) x_forward(xe, p_c1[e], 1, true, 0, 1 + e, true);      // critic(obs, actions)            fql.py:36
-            for (int e = 0; e < 2; ++e) x_forward(xe, p_ct[e], 1, false, 0, 3 + e, false);    // target critic(next_obs, a')     fql.py:28
-            x_forward(xe, p_bc, 1, true, 0, 5, true);                                          // BC flow on (obs, x_t, t)        fql.py:58
-            for (int e = 0; e < 2; ++e) x_forward(xe, p_c2[e], 1, true, 0, 6 + e, false);     // critic(obs, clip(mu))           fql.py:70
-            for (int e = 0; e < 2; ++e) x_backward(xe, p_c2[e], 0, true, 0, 16 + 8 * e, false);   // dQ/da: what the one-step actor's backward waits for
-            for (int e = 0; e < 2; ++e) x_backward(xe, p_c1[e], 0, false, 1, 8 * e, true);
-            x_backward(xe, p_bc, 0, false, 2, 0, true);
-            {
-                const size_t first = xe.size();
-                x_backward(xe, p_os_bwd, B, false, 3, 0, true);
-                for (size_t i = first; i < xe.size(); ++i) xe[i].chain = true;   // the tail of the critical path
-            }
-            {   // info scalars: per-XCD partial sums
-                XEmit e;
-                XOp& o = e.op;
-                o.kind = XK_METRICS; o.member0 = 9; o.nblk = 1; o.blk_stride = B;
-                o.p0 = p_c1[0].out; o.p1 = p_c1[1].out; o.p2 = p_ct[0].out; o.p3 = p_ct[1].out; o.p4 = w_rew; o.p5 = w_mask;
-                o.A = p_bc.out; o.W = vel; o.bias = p_os.out; o.Zmul = tgt; o.ln_g = p_c2[0].out; o.ln_b = p_c2[1].out; o.o0 = w_act;
-                o.f0 = cfg.discount; o.i1 = cfg.q_agg;
-                e.reads = {p_c1[0].out, p_c1[1].out, p_ct[0].out, p_ct[1].out, p_bc.out, p_os.out, tgt, p_c2[0].out, p_c2[1].out};
-                e.writes = {xpart};
-                xe.push_back(e);
-            }
-            // phases: an op runs one phase of ITS team after every op of that team it conflicts with (RAW, WAW, WAR), and its phase waits for
-            // the phase of every op of the other team it conflicts with
-            {
-                std::map<const void*, int> last_writer;
-                std::map<const void*, std::vector<int>> readers;
-                std::vector<int> waitmax[2];   // per team and phase: how many phases of the other team it waits for
-                for (int i = 0; i < (int)xe.size(); ++i) {
-                    XEmit& e = xe[i];
-                    int lv = 0, wt = 0;
-                    auto dep = [&](int d) {
-                        if (d == i) return;
-                        if (xe[d].chain == e.chain) lv = std::max(lv, xe[d].level + 1);
-                        else wt = std::max(wt, xe[d].level + 1);
-                    };
-                    for (const void* r : e.reads) { auto it = last_writer.find(r); if (it != last_writer.end()) dep(it->second); }
-                    for (const void* w : e.writes) {
-                        auto it = last_writer.find(w); if (it != last_writer.end()) dep(it->second);
-                        auto ir = readers.find(w); if (ir != readers.end()) for (int r : ir->second) dep(r);
-                    }
-                    // no cycles between the teams: the phases of the other team this op waits for must not themselves wait for this op's phase,
-                    // so the op goes behind every phase of its own team that they wait for
-                    const int me = e.chain ? 0 : 1, other = 1 - me;
-                    for (int q = 0; q < wt && q < (int)waitmax[other].size(); ++q) lv = std::max(lv, waitmax[other][q]);
-                    e.level = lv; e.wait = wt;
-                    if ((int)waitmax[me].size() <= lv) waitmax[me].resize(lv + 1, 0);
-                    waitmax[me][lv] = std::max(waitmax[me][lv], wt);
-                    for (const void* r : e.reads) readers[r].push_back(i);
-                    for (const void* w : e.writes) { last_writer[w] = i; readers.erase(w); }
-                }
-            }
-            std::vector<XOp> ops;
-            std::vector<XPhase> phases;
-            double macs = 0.0;
-            int nph[2] = {0, 0};
-            const int nct = (B / 128 >= 2 && !getenv("FQL_XCD_ONE_CHAIN")) ? 2 : 1;   // two chain pipelines (even / odd row tiles) once an XCD holds two row tiles
-            int chain_p0 = 0, chain_len = 0;
-            for (int team = 0; team < 2; ++team) {   // group 0 = team 0 (critical path), group 1 = teams 2 and 3 (one shared phase list)
-                int maxlv = -1;
-                for (const XEmit& e : xe) if (e.chain == (team == 0)) maxlv = std::max(maxlv, e.level);
-                int waited = 0;   // (a team's phases run in order: a wait already made covers the later ones)
-                for (int lv = 0; lv <= maxlv; ++lv) {
-                    XPhase ph{};
-                    ph.first = (int)ops.size();
-                    std::vector<const XEmit*> sel;
-                    int wt = 0;
-                    for (const XEmit& e : xe)
-                        if (e.chain == (team == 0) && e.level == lv) { sel.push_back(&e); wt = std::max(wt, e.wait); }
-                    if (wt <= waited) wt = 0; else waited = wt;
-                    if (team == 0) {
-                        for (const XEmit* e : sel) ops.push_back(e->op);
-                        ph.count = ph.count_a = (int)sel.size();
-                        ph.wait[2] = ph.wait[3] = wt;   // the other group's phases are those of teams 2 and 3
-                        if (ph.count == 1 && sel[0]->op.kind == XK_CHAIN_L0 && sel[0]->op.step == 0) { ph.chain = fs * nh; chain_p0 = lv; chain_len = fs * nh; }
-                        // the first phase behind the chain needs the second pipeline's last step too
-                        if (nct == 2 && chain_len > 0 && lv == chain_p0 + chain_len) ph.wait[1] = chain_len;
-                    } else {
-                        // deal the ops of the phase to teams 2 and 3: heaviest first, each to the lighter team
-                        std::sort(sel.begin(), sel.end(), [](const XEmit* x, const XEmit* y) { return x->macs > y->macs; });
-                        std::vector<const XEmit*> ta, tb;
-                        double wa = 0.0, wb = 0.0;
-                        for (const XEmit* e : sel) {
-                            const double w = e->macs + 1e6;
-                            if (wa <= wb) { ta.push_back(e); wa += w; } else { tb.push_back(e); wb += w; }
-                        }
-                        for (const XEmit* e : ta) ops.push_back(e->op);
-                        for (const XEmit* e : tb) ops.push_back(e->op);
-                        ph.count = (int)sel.size(); ph.count_a = (int)ta.size();
-                        ph.wait[0] = wt;
-                    }
-                    phases.push_back(ph);
-                }
-                nph[team] = maxlv + 1;
-            }
-            for (const XEmit& e : xe) macs += e.macs;
-            if (getenv("FQL_DUMP")) {
-                fprintf(stderr, "[fql] xcd program: %zu ops, team 0: %d phases, teams 2 / 3: %d phases, %d chain pipeline(s)\n", ops.size(), nph[0], nph[1], nct);
-                for (size_t pi = 0; pi < phases.size(); ++pi) {
-                    fprintf(stderr, "[fql]  %s phase %2d (waits %d %d %d %d; %d ops to the first team):", pi < (size_t)nph[0] ? "team 0" : "teams 2/3", (int)(pi < (size_t)nph[0] ? pi : pi - nph[0]),
-                            phases[pi].wait[0], phases[pi].wait[1], phases[pi].wait[2], phases[pi].wait[3], phases[pi].count_a);
-                    for (int i = phases[pi].first; i < phases[pi].first + phases[pi].count; ++i) fprintf(stderr, " k%d(%dx%d,f%x)", ops[i].kind, ops[i].K, ops[i].N, ops[i].flags);
-                    fprintf(stderr, "\n");
-                }
-            }
-            auto up = [&](const void* src, size_t bytes) -> void* {
-                void* d = dalloc(ws_allocs, bytes / sizeof(float) + 4);
-                HIP_CHECK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
-                return d;
-            };
-            Op xo{};
-            xo.type = OP_XCD;
-            XcdArgs& a = xo.xcd;
-            a.ops = (const XOp*)up(ops.data(), ops.size() * sizeof(XOp));
-            a.phases = (const XPhase*)up(phases.data(), phases.size() * sizeof(XPhase));
-            a.nphase0 = nph[0]; a.nphase1 = nph[1];
-            a.nct = nct; a.chain_p0 = chain_p0;
-            a.B = B; a.R = B / 8; a.RT = B / 128;
-            a.sync = xsync; a.xpart = xpart;
-            a.chain_nl = nh - 1; a.H = H;
-            if ((size_t)FQL_XCD_LDS_FLOATS(a.chain_nl, H) * sizeof(float) > 160 * 1024) a.chain_nl = 0;   // (deeper nets: the chain streams its kernels like every other pass)
-            for (int l = 1; l < nh && l - 1 < 7; ++l) { a.chain_w[l - 1] = P + nb.layers[l].w; a.chain_b[l - 1] = P + nb.layers[l].b; }
-            a.hc[0] = Hc[0]; a.hc[1] = Hc[1]; a.c0 = C0;
-            a.w0 = P + nb.layers[0].w; a.w4 = P + nb.layers[nh].w; a.b4 = P + nb.layers[nh].b;
-            a.x_eu = X_eu; a.vp = xvp; a.tgt = tgt;
-            a.od = od; a.ad = ad; a.ap = ap; a.in_p = inp_b; a.fs = fs;
-            a.lds_floats = FQL_XCD_LDS_FLOATS(a.chain_nl, H);
-            a.skip_team = getenv("FQL_XCD_SKIP_TEAM") ? atoi(getenv("FQL_XCD_SKIP_TEAM")) : -1;
-#ifdef FQL_XSTAMPS
-            a.stamp_stride = std::max(std::max(nph[0], nph[1]), chain_len + 1);
-            a.stamps = (unsigned long long*)dalloc(ws_allocs, ((size_t)1024 * a.stamp_stride * 4 + 256 * 25) * 2);
-            a.stamps2 = a.stamps + (size_t)1024 * a.stamp_stride * 4;
-            a.stamp_phase = getenv("FQL_XSTAMP_PHASE") ? atoi(getenv("FQL_XSTAMP_PHASE")) : -1;
-            a.stamp_team = getenv("FQL_XSTAMP_TEAM") ? atoi(getenv("FQL_XSTAMP_TEAM")) : 0;
-            if (mode == 0) x_stamps = a.stamps;
-#endif
-            x_lds = (size_t)a.lds_floats * sizeof(float);
-            x_nphase = std::max(std::max(nph[0], nph[1]), chain_len + 1); x_nops = (int)ops.size();
-            xo.reads = {X_os, X_bc, X_eu, X_c1, X_c2, X_ct, vel, w_rew, w_mask, w_act, X_e0};
-            for (const XEmit& e : xe) for (const void* w : e.writes) xo.writes.push_back(w);
-            xo.fin_mode = 0;
-            xcd_macs = macs;
-            push(pr, xo);
-            // weight gradients (and LayerNorm scale / bias gradients): sums over the whole batch, one launch behind the persistent one
-            for (int e = 0; e < 2; ++e) x_wgrads(pr, p_c1[e], 0, B);
-            x_wgrads(pr, p_bc, 0, B);
-            x_wgrads(pr, p_os_bwd, B, B);
-        }
-        if (mode != 1) {
-            Op a{};
-            a.type = OP_ADAM;
-            a.adam_c0 = 0; a.adam_n = -1;
-            a.reads = {st};
-            a.writes = {d_partials};
-            for (int ni : {NET_C0, NET_C1, NET_BC, NET_OS})
-                for (const Layer& L : nets[ni].layers) {
-                    a.reads.push_back(G + L.w); a.reads.push_back(G + L.b);
-                    a.writes.push_back(P + L.w);
-                    if (L.ln) { a.reads.push_back(G + L.g); a.reads.push_back(G + L.be); a.writes.push_back(P + L.g); }
-                }
-            if (mode == 0) a.reads.push_back(xpart);   // (behind the persistent launch: it reads the parameters this launch rewrites)
-            push(pr, a);
-            Op f{};
-            f.type = OP_FINALIZE;
-            f.fin_mode = 3;   // grad stats + bookkeeping + the info scalars from the per-XCD partials
-            f.reads = {d_partials, xpart};
-            f.writes = {&st->info[0], st};
-            push(pr, f);
-        }
-    }
-    double xcd_macs = 0.0;
-    unsigned long long* x_stamps = nullptr;
 
     void build_workspace(int batch) {
         if (batch <= 0 || batch % 16 != 0) invalid("batch_size must be a positive multiple of 16 (got %d)", batch);
@@ -3277,6 +2878,27 @@ struct fql_engine {
                 }
             }
         }
+        use_xchain = xchain_eligible();
+        if (use_xchain) {
+            const Net& nb = nets[NET_BC];
+            x_wlds = getenv("FQL_XCHAIN_WLDS") == nullptr || atoi(getenv("FQL_XCHAIN_WLDS")) != 0;   // (=0: kernels streamed into registers, 16 KB of LDS: 319 us for the chain)
+            x_lds = (size_t)FQL_XCHAIN_LDS_FLOATS(nb.nl() - 2, nb.layers[0].out_p, x_wlds) * sizeof(float);
+            int per_cu = 0;   // every workgroup waits for its XCD's other 31: all 256 must be resident, one per CU
+            const void* kf = x_wlds ? (const void*)fql_xchain_kernel<true> : (const void*)fql_xchain_kernel<false>;
+            hipError_t oe = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x_lds);
+            if (oe == hipSuccess) oe = x_wlds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fql_xchain_kernel<true>, 256, x_lds)
+                                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fql_xchain_kernel<false>, 256, x_lds);
+            if (oe != hipSuccess || per_cu < 1) {
+                (void)hipGetLastError();
+                use_xchain = false;
+            } else {
+                xsync = (unsigned*)dalloc(W, 17 * 32);
+                xvp = dalloc(W, (size_t)XCH_NMEM * B * 16);
+#ifdef FQL_XSTAMPS
+                x_stamps = (unsigned long long*)dalloc(W, (size_t)256 * 64 * 2 * 2);
+#endif
+            }
+        }
         if (visual) {
             const size_t ib = (size_t)cfg.img_h * cfg.img_w * cfg.img_c;
             img_all = (unsigned char*)dalloc(W, (2 * (size_t)B * ib + 3) / 4 + 4);
@@ -3334,22 +2956,6 @@ struct fql_engine {
         }
         launches_per_update = prog_full.exec ? (int64_t)prog_full.launches.size()
                                              : (int64_t)prog_fwdbwd.launches.size() + (int64_t)prog_opt.launches.size();
-        if (xcd_eligible()) {
-            xsync = (unsigned*)dalloc(W, 41 * 32); xpart = dalloc(W, 8 * 16); xvp = dalloc(W, (size_t)XCD_NMEM * B * 16);
-            build_xcd_program(prog_xfull, 0);
-            build_xcd_program(prog_xbegin, 1);
-            build_xcd_program(prog_xopt, 2);
-            HIP_CHECK(hipFuncSetAttribute((const void*)fql_xcd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x_lds));
-            int per_cu = 0;   // every workgroup waits for its XCD's other 31: all 256 must be resident, one per CU
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fql_xcd_kernel, 1024, x_lds) != hipSuccess || per_cu < 1) {
-                (void)hipGetLastError();
-            } else {
-                schedule(prog_xfull, W); schedule(prog_xbegin, W); schedule(prog_xopt, W);
-                capture(prog_xfull); capture(prog_xbegin); capture(prog_xopt);
-                xcd_ok = true;
-                launches_per_update = (int64_t)prog_xfull.launches.size();
-            }
-        }
         src_valid = false;
     }
 
@@ -3888,18 +3494,8 @@ int fql_set_step(fql_handle h, int64_t adam_count, int64_t train_step) {
 // NULL = the engine's own stream; FQL_STREAM_LEGACY ((void*)1 == hipStreamLegacy) = the legacy default stream, i.e. the stream
 // torch's *default* stream maps to (its handle reads 0, which cannot be told from "no stream" here); anything else is a hipStream_t.
 static hipStream_t pick(fql_handle h, void* s) { return s ? (hipStream_t)s : h->stream; }
-// the whole-update program in use: the XCD-resident one where the configuration allows it (fql_xcd.h), else the launch-per-level graph
-static Program* full_prog(fql_handle h) { return h->xcd_ok ? &h->prog_xfull : (h->prog_full.exec ? &h->prog_full : nullptr); }
 
 static void run_program(fql_handle h, Program& pr, hipStream_t s) {
-    const bool xprog = &pr == &h->prog_xfull || &pr == &h->prog_xbegin || &pr == &h->prog_xopt;
-    if (xprog) {
-        if (&pr != &h->prog_xbegin) h->wfrag_dirty = true;   // new parameters; the launch-per-level programs' kernel copies are refreshed when next needed
-        if (getenv("FQL_NO_GRAPH")) h->run_launches(pr, s);
-        else HIP_CHECK(hipGraphLaunch(pr.exec, s));
-        return;
-    }
-    if (h->wfrag_dirty && &pr != &h->prog_opt) { h->refresh_chain_weights(s); h->wfrag_dirty = false; }
     static const bool no_graph = getenv("FQL_NO_GRAPH") != nullptr;
     static const bool eager_lanes = getenv("FQL_NO_GRAPH") && atoi(getenv("FQL_NO_GRAPH")) == 2;   // eager launches on the lane streams
     static const bool split_default = getenv("FQL_SPLIT_DEFAULT") != nullptr;  // experiment: host-launched lane graphs
@@ -3936,11 +3532,11 @@ int fql_update_end(fql_handle h, float* info13, void* stream) {
 }
 int fql_update(fql_handle h, const float* obs, const float* act, const float* rew, const float* mask, const float* nobs,
                int batch_size, const fql_noise* noise, float* info13, void* stream) {
-    if (h && full_prog(h) && !h->began) {
+    if (h && h->prog_full.exec && !h->began) {
         FQL_TRY(h, {
             hipStream_t s = pick(h, stream);
             h->source_from_batch(obs, act, rew, mask, nobs, batch_size, noise, 1, s);
-            run_program(h, *full_prog(h), s);
+            run_program(h, h->prog_full, s);
             h->finish_info(info13, FQL_NUM_INFO, s);
         });
     }
@@ -4158,7 +3754,7 @@ int fql_update_balanced(fql_handle h, const int64_t* idx_dataset, const int64_t*
     FQL_TRY(h, {
         hipStream_t s = pick(h, stream);
         h->source_balanced(idx_dataset, idx_replay, crop_froms, batch_size, noise, s);
-        if (full_prog(h)) run_program(h, *full_prog(h), s);
+        if (h->prog_full.exec) run_program(h, h->prog_full, s);
         else { run_program(h, h->prog_fwdbwd, s); run_program(h, h->prog_opt, s); }
         h->finish_info(info13, FQL_NUM_INFO, s);
     });
@@ -4215,11 +3811,11 @@ int fql_grad_buckets(fql_handle h, size_t offsets[2], size_t lengths[2]) {
 int fql_update_from_dataset(fql_handle h, const int64_t* idx, int batch_size, int64_t lo, int64_t hi, const fql_noise* noise,
                             float* info13, void* stream) {
     if (h && h->visual) return fql_update_from_frames(h, idx, nullptr, batch_size, lo, hi, noise, info13, stream);
-    if (h && full_prog(h) && !h->began) {
+    if (h && h->prog_full.exec && !h->began) {
         FQL_TRY(h, {
             hipStream_t s = pick(h, stream);
             h->source_from_dataset(idx, batch_size, lo, hi, noise, s);
-            run_program(h, *full_prog(h), s);
+            run_program(h, h->prog_full, s);
             h->finish_info(info13, FQL_NUM_INFO, s);
         });
     }
@@ -4292,13 +3888,12 @@ void* fql_stream(fql_handle h) { return h ? (void*)h->stream : nullptr; }
 // in a rocprofv3 trace) to compare with rocprofv3's per-kernel durations.
 extern "C" int fql_profile_update(fql_handle h, int batch_size, int cap, int* type, int* lane, int* grid, float* us, double* macs, float* null_us) {
     if (!h || !type || !us) return FQL_E_INVALID;
-    if (!full_prog(h)) { h->err = "no single-graph update program"; return FQL_E_STATE; }
+    if (!h->prog_full.exec) { h->err = "no single-graph update program"; return FQL_E_STATE; }
     try {
         hipStream_t s = h->stream;
         if (null_us) *null_us = 0.f;   // (no calibration needed: the events ride on the dispatches)
         h->source_from_dataset(nullptr, batch_size, 0, 0, nullptr, s);
-        Program& pr = *full_prog(h);
-        if (h->xcd_ok) h->wfrag_dirty = true;
+        Program& pr = h->prog_full;
         const int n = (int)pr.launches.size();
         std::vector<hipEvent_t> ev(2 * n);
         for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
@@ -4320,23 +3915,6 @@ extern "C" int fql_profile_update(fql_handle h, int batch_size, int cap, int* ty
         return std::min(n, cap);
     } catch (const Invalid& e) { h->prof_a = h->prof_b = nullptr; h->err = e.msg; return FQL_E_INVALID; }
     catch (const HipError& e) { h->prof_a = h->prof_b = nullptr; h->err = e.msg; return FQL_E_HIP; }
-}
-
-// Diagnostic only: the sticky error word of the XCD-resident launch (0 = fine, 1 = a wait timed out, 2 = more than 32 workgroups on an XCD)
-extern "C" int fql_debug_xcd_err(fql_handle h, unsigned* out) {
-    if (!h || !h->xsync || !out) return FQL_E_NOTFOUND;
-    if (hipDeviceSynchronize() != hipSuccess) return FQL_E_HIP;
-    return hipMemcpy(out, h->xsync + 40 * 32, 4, hipMemcpyDeviceToHost) == hipSuccess ? FQL_OK : FQL_E_HIP;
-}
-
-// Diagnostic only (-DFQL_XSTAMPS builds): the phase stamps of the last XCD-resident launch, [256][phases][4] ticks of 10 ns
-extern "C" int fql_debug_xcd_stamps(fql_handle h, unsigned long long* out, size_t cap, int* nphase) {
-    if (!h || !h->x_stamps) return FQL_E_NOTFOUND;
-    if (nphase) *nphase = h->x_nphase;
-    const size_t n = (size_t)1024 * h->x_nphase * 4 + 256 * 25;
-    if (cap < n) return FQL_E_INVALID;
-    if (hipDeviceSynchronize() != hipSuccess) return FQL_E_HIP;
-    return hipMemcpy(out, h->x_stamps, n * 8, hipMemcpyDeviceToHost) == hipSuccess ? FQL_OK : FQL_E_HIP;
 }
 
 // Diagnostic only (not in include/fql_amd.h): copy a workspace buffer of the last update to the host, so tests can look at what the

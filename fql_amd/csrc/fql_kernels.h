@@ -214,7 +214,6 @@ struct LnBwdTask {
     const float* dq;
     const float* wq;
     int ldq, ldw;
-    int cols_only;       // 1: only the column-sum tiles (dgamma, dbeta) - the row part ran inside the XCD-resident launch (fql_xcd.h)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1890,15 +1889,16 @@ struct PrepArgs {
     int tl;   // timeline id (diagnostics)
     int part; // 0: every output; 1: the critical lane's inputs only (X_eu, X_e0); 2: everything else (one launch per lane: neither lane
               //    then waits for the other at the start of the update)
-    unsigned* xsync;  // XCD-resident launch behind this one: its arrival flags and tickets (32-word slots 0..39; slot 40 is the sticky error word) are zeroed here (fql_xcd.h), or null
+    unsigned* xsync;  // the XCD-resident Euler chain behind this launch (fql_xchain.h): its arrival flags and tickets (32-word slots 0..15; slot 16 is the
+                      // sticky error word) are zeroed here, or null
 };
 
 // agents/fql.py:52-56 (x_t, vel), :144-150 (noise), utils/datasets.py:64-100 (index draw + gather),
 // utils/networks.py:191,229-231 (concatenate) -- one pass builds every network input of the step.
 __global__ __launch_bounds__(FQL_THREADS) void fql_prep_kernel(PrepArgs P) {
     tl_enter(P.tl);
-    if (P.xsync && blockIdx.x == 0)
-        for (int i = threadIdx.x; i < 40 * 32; i += FQL_THREADS) P.xsync[i] = 0u;   // (slot 40, the error word, stays)
+    if (P.xsync && blockIdx.x == 0 && P.part != 2)
+        for (int i = threadIdx.x; i < 16 * 32; i += FQL_THREADS) P.xsync[i] = 0u;
     const SrcDesc& S = *P.src;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + wave;
@@ -2232,10 +2232,6 @@ struct FinalizeArgs {
     const int* leaf_range;   // [nleaves + 1] chunk index ranges (chunks of a leaf are contiguous)
     int n_chunks, nleaves, do_grad_stats;
     int tl;
-    // XCD-resident update: per-XCD partial sums of the loss / metric scalars [8][16] (fql_xcd.h XK_METRICS), folded here in XCD order
-    const float* xpart;
-    int xB, xad;
-    float xalpha;
 };
 // grad/max, grad/min, grad/norm = sum over leaves of ||g_leaf||_2 (utils/flax_utils.py:139-157); target-critic leaves
 // contribute zeros, which bound grad/max >= 0 >= grad/min (F5).  Also advances optax count / TrainState.step / RNG step.
@@ -2244,27 +2240,6 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_finalize_kernel(FinalizeArgs 
     __shared__ float leafn[256];
     DevState* st = A.st;
     tl_enter(A.tl);
-    if (A.xpart && threadIdx.x == 0) {   // agents/fql.py:39-44,85-92
-        float s[9];
-        for (int k = 0; k < 9; ++k) s[k] = (k == 2) ? -INFINITY : (k == 3 ? INFINITY : 0.f);
-        for (int g = 0; g < 8; ++g)
-            for (int k = 0; k < 9; ++k) {
-                const float v = A.xpart[16 * g + k];
-                s[k] = (k == 2) ? fmaxf(s[k], v) : (k == 3 ? fminf(s[k], v) : s[k] + v);
-            }
-        const float fB = (float)A.xB, fn = (float)(A.xB * A.xad);
-        st->info[0] = s[0] / (2.0f * fB);
-        st->info[1] = s[1] / (2.0f * fB);
-        st->info[2] = s[2];
-        st->info[3] = s[3];
-        st->info[5] = s[4] / fn;
-        st->info[6] = s[5] / fn;
-        const float qmean = s[6] / fB;
-        st->info[7] = -qmean;
-        st->info[8] = qmean;
-        st->info[9] = s[8] / fn;
-        st->info[4] = st->info[5] + A.xalpha * st->info[6] + st->info[7];
-    }
     if (!A.do_grad_stats) return;
     float mx = -INFINITY, mn = INFINITY;
     for (int cidx = threadIdx.x; cidx < A.n_chunks; cidx += FQL_THREADS) {
