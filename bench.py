@@ -199,6 +199,28 @@ def bench_bf16x3(args, cfg, ds, od, ad, B, torch):
     return res
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks of this script (one per GPU, RCCL over xGMI) with the
+    torch.distributed environment the launcher would have set, relay rank 0's ONE json line on stdout, return the worst exit code.
+    The parent touches no GPU (a process that has initialised HIP must not exec or fork GPU children on this pool)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -219,6 +241,13 @@ def main():
                          "(fql_config.precision = 2; reported against the bf16 peak / 3)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))   # (this process has made no GPU call: it only starts the ranks and relays rank 0's line)
+    if os.environ.get('FQL_BENCH_SPAWN_DRYRUN'):    # tests of the launcher path (no GPU): a rank reports the environment it was started with
+        if os.environ.get('RANK', '0') == '0':
+            print(json.dumps({k: os.environ.get(k) for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')} | {'gpus': args.gpus}))
+        return
+
     import torch
     import fql_amd
     from fql_amd.parallel import DataParallelFQL
@@ -228,8 +257,9 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks for --gpus N (or none: bench.py starts them itself)')
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f'rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPU(s) visible')
     torch.cuda.set_device(local_rank)
     dist = None
     force_dp = bool(os.environ.get('FQL_BENCH_FORCE_DP'))  # exercise the RCCL path on one GPU (torchrun --nproc-per-node 1)
@@ -261,8 +291,12 @@ def main():
         agent = fql_amd.FQLAgent.create(seed, ds['observations'][:1], ds['actions'][:1], cfg)
         up_kw = {}
     dp = DataParallelFQL(agent, overlap=os.environ.get('FQL_DP_OVERLAP', '1') != '0') if dist is not None else None
+    dp_mode = None
     if dp is not None:
         dp.upload_shard(ds, **up_kw)          # this rank's rows only
+        # nobody is there to choose between the overlapped (bucketed, two streams) and the plain (one all-reduce) step at this world size:
+        # time both with the collectives live and keep the faster (FQL_DP_OVERLAP=0 / 1 pins it)
+        dp_mode = dp.autotune(batch_size=B, steps=40) if 'FQL_DP_OVERLAP' not in os.environ else {'chosen': 'overlapped' if dp.buckets is not None else 'plain', 'pinned': True}
     else:
         agent.upload_dataset(ds, **up_kw)
 
@@ -308,8 +342,10 @@ def main():
         out = {
             'metric': 'FQL gradient-steps/s (batch=256)', 'value': round(steps_per_s * world, 2), 'unit': 'grad-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt * 1e3 / args.steps, 5),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else ('bf16x3' if visual else 'bf16x3'), 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'bf16x3', 'data': 'synthetic',
             'config': {'workload': work, 'parallelism': f'dp{world}', 'samples_per_s': round(steps_per_s * world * B, 1)},
+            'rccl_ranks': (dist.get_world_size() if dist is not None else 1), 'backend': (dist.get_backend() if dist is not None else None),
+            'device': torch.cuda.current_device(), 'data_parallel_step': dp_mode,
             'whole_update': {'flop': flop_per_step, 'wall_us': round(step_us_wall, 3), 'achieved_tflops': round(whole, 3),
                              ('frac_of_fp32_matrix_peak' if peak_tf == FP32_MATRIX_PEAK_TFLOPS else 'frac_of_bf16_matrix_peak_over_3'): round(whole / peak_tf, 4),
                              'kernel_launches_per_update': st['launches_per_update']},

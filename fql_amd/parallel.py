@@ -137,6 +137,32 @@ class DataParallelFQL:
         self.shard_rows = hi - lo
         return lo, hi
 
+    def autotune(self, batch_size=None, steps=40):
+        """Time the overlapped (bucketed, two streams) and the plain (one all-reduce) step on the uploaded shard with the collectives live and
+        keep the faster on every rank (the slowest rank's time decides: MAX over ranks).  These are real updates - call it during warm-up.
+        Returns {'chosen', 'overlapped_us', 'plain_us'}; without the two-lane program only the plain step exists."""
+        import time
+        import torch
+        if not self.on_gpu or self.buckets is None:
+            return {'chosen': 'plain', 'overlapped_us': None, 'plain_us': None}
+        saved = self.buckets
+        res = {}
+        for name, b in (('overlapped', saved), ('plain', None)):
+            self.buckets = b
+            for _ in range(5):
+                self.update_from_dataset(batch_size=batch_size)
+            self.dist.barrier(group=self.pg); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.update_from_dataset(batch_size=batch_size)
+            torch.cuda.synchronize()
+            t = torch.tensor([(time.perf_counter() - t0) / steps * 1e6], dtype=torch.float64, device=self.grads.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.pg)
+            res[name] = float(t.item())
+        chosen = 'overlapped' if res['overlapped'] <= res['plain'] else 'plain'
+        self.buckets = saved if chosen == 'overlapped' else None
+        return {'chosen': chosen, 'overlapped_us': round(res['overlapped'], 1), 'plain_us': round(res['plain'], 1)}
+
     # -- the step ------------------------------------------------------------------------------------------------
     def update_from_dataset(self, n_rows=None, batch_size=None, idxs=None, noise=None):
         """One synchronous data-parallel step.  After `upload_shard` the device holds this rank's rows only and indices are drawn

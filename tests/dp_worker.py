@@ -1,6 +1,6 @@
 """Worker of tests/test_gpu_parallel.py::test_two_processes_on_one_gpu_equal_one_step_on_the_concatenated_batch: one rank of a
 world-size-2 DataParallelFQL run (gloo: RCCL refuses two ranks on one device; the wrapper's logic is backend-agnostic), both ranks on
-cuda:0.  argv: rank port out_dir overlap(0|1)."""
+cuda:0.  argv: rank port out_dir overlap(0|1) [B hidden]."""
 import os
 import sys
 
@@ -20,8 +20,10 @@ def main():
     os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = port
     dist.init_process_group('gloo', rank=rank, world_size=2)
     torch.cuda.set_device(0)
-    od, ad, B = 29, 8, 32
-    cfg, ds, _, _ = make_problem(od, ad, B, (64, 64, 64, 64), seed=71)
+    od, ad = 29, 8
+    B = int(sys.argv[5]) if len(sys.argv) > 5 else 32
+    H = int(sys.argv[6]) if len(sys.argv) > 6 else 64
+    cfg, ds, _, _ = make_problem(od, ad, B, (H, H, H, H), seed=71)
     agent = fql_amd.FQLAgent.create(0, ds['observations'][:1], ds['actions'][:1], cfg)      # the SAME seed on both ranks
     if rank == 0:                                           # only rank 0 holds the "restored" state: params away from init, Adam state
         agent.set_params(randomize_params(agent.get_params(), seed=72))
@@ -38,7 +40,9 @@ def main():
         dp.update_from_dataset(batch_size=B, idxs=idx_global[mine], noise={k: v[mine] for k, v in nz.items()})
     torch.cuda.synchronize()
     leaves = dict(O.tree_leaves_with_path(agent.get_params()))
-    np.savez(os.path.join(out, f'rank{rank}.npz'), **{k.replace('/', '|'): v for k, v in leaves.items()})
+    nu = dict(O.tree_leaves_with_path(agent.get_opt_state()['nu']))
+    np.savez(os.path.join(out, f'rank{rank}.npz'), **{k.replace('/', '|'): v for k, v in leaves.items()},
+             **{'nu|' + k.replace('/', '|'): v for k, v in nu.items()})
     # engine-RNG step: ranks must draw DIFFERENT noise and rows (rank mixed into the device RNG key)
     dp.update_from_dataset(batch_size=B)
     torch.cuda.synchronize()

@@ -26,33 +26,7 @@ def _agent(cfg, batch, seed=0):
     return fql_amd.FQLAgent.create(seed, batch['observations'][:1], batch['actions'][:1], cfg)
 
 
-def _assert_step_matches(agent, ref, cfg, batch, noise):
-    """One update on both sides: 13 infos, every leaf's gradient (Adam mu / 0.1 after the first step), nu, post-step parameters."""
-    _, _, g_ref = ref.grads(batch, noise)
-    _, info_u = agent.update(batch, noise=noise)
-    _, info_ru = ref.update(batch, noise)
-    assert_info_close(info_u, info_ru, rtol=5e-5, atol=5e-6)
-    opt = agent.get_opt_state()
-    assert opt['count'] == 1 and opt['step'] == 2
-    mu, nu = leaf_dict(opt['mu']), leaf_dict(opt['nu'])
-    new, new_ref = leaf_dict(agent.get_params()), leaf_dict(ref.params)
-    lr = cfg['lr']
-    worst = (0.0, None)
-    for p, g in leaf_dict(g_ref).items():
-        scale = np.abs(g).max()
-        tol = 2e-5 * scale + 1e-9
-        err = np.abs(mu[p] / 0.1 - g).max()
-        worst = max(worst, (err / max(scale, 1e-30), p))
-        np.testing.assert_allclose(mu[p] / 0.1, g, rtol=0, atol=tol, err_msg=f'grad {p}')
-        np.testing.assert_allclose(nu[p] / 0.001, g * g, rtol=1e-4, atol=tol * scale + 1e-12, err_msg=f'nu {p}')
-        d = np.abs(new[p] - new_ref[p])
-        stable = np.abs(g) > 50 * tol
-        if 'target' in p:
-            assert d.max() <= 1e-6, p
-        else:
-            assert d[stable].max(initial=0) <= 2e-6, (p, d[stable].max())
-            assert d.max() <= 2 * lr + 1e-6, p
-    return worst
+from tests.util import assert_step_matches as _assert_step_matches  # noqa: E402  (shared with the data-parallel program tests)
 
 
 @pytest.mark.parametrize('od,ad,B,alpha', [(29, 8, 256, 10.0), (40, 4, 1024, 300.0)], ids=['configs1', 'configs2'])

@@ -233,3 +233,29 @@ def test_two_rank_step_equals_one_rank_step_on_concatenated_batch_through_the_wr
     one.update_end()
     for (p, a), (_, b) in zip(tree_flatten(ranks[0].ref.params), tree_flatten(one.ref.params)):
         np.testing.assert_allclose(a, b, rtol=0, atol=1e-12, err_msg=p)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher (how the driver calls it): the parent, which never touches a GPU, starts N ranks with the
+    torch.distributed environment, relays rank 0's single line and returns the worst exit code.  Here (no GPU) up to device selection:
+    every rank stops at 'only 0 GPU(s) visible' and the parent reports failure; with the dry-run hook rank 0's environment comes back."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       env=dict(env, FQL_BENCH_SPAWN_DRYRUN='1'), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines           # ONE line on stdout: rank 0's
+    got = json.loads(lines[0])
+    assert got['RANK'] == '0' and got['WORLD_SIZE'] == '2' and got['MASTER_ADDR'] == '127.0.0.1' and got['gpus'] == 2
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0
+        assert r.stderr.count('GPU(s) visible') == 2, r.stderr[-2000:]     # both ranks got as far as choosing their device
+        assert r.stdout.strip() == ''
