@@ -77,41 +77,81 @@ class _Arg:
             self.ptr = a.ctypes.data
 
 
-class LazyInfo(dict):
-    """The info dict of one update, read from the device only when first looked at (the reference's `update` returns device
-    scalars that main.py:276 reads at log time, so its training loop never synchronises per step).  Behaves as a dict of 13 floats;
-    the first access blocks until that update has run.  Holding it across more than 64 later lazy updates without reading it
-    raises (the engine keeps 64 snapshots)."""
+class _Pending:
+    """The 13 scalars of one update, fetched from the engine's pinned snapshot ring on first use (one blocking wait, then cached)."""
 
     def __init__(self, agent, ticket):
-        super().__init__()
-        self._agent, self._ticket, self._done = agent, ticket, False
+        self.agent, self.ticket, self.vals = agent, ticket, None
 
-    def _fill(self):
-        if not self._done:
+    def get(self):
+        if self.vals is None:
             buf = (C.c_float * _cabi.FQL_NUM_INFO)()
-            self._agent._check(self._agent._lib.fql_info_wait(self._agent._h, self._ticket, buf))
-            super().update({k: float(buf[i]) for i, k in enumerate(INFO_KEYS)})
-            self._done, self._agent = True, None
+            self.agent._check(self.agent._lib.fql_info_wait(self.agent._h, self.ticket, buf))
+            self.vals = [float(buf[i]) for i in range(_cabi.FQL_NUM_INFO)]
+            self.agent = None
+        return self.vals
 
-    def __getitem__(self, k): self._fill(); return super().__getitem__(k)
-    def __iter__(self): self._fill(); return super().__iter__()
-    def __len__(self): self._fill(); return super().__len__()
-    def __contains__(self, k): self._fill(); return super().__contains__(k)
-    def __repr__(self): self._fill(); return super().__repr__()
-    def __eq__(self, o):
-        self._fill()
-        if isinstance(o, LazyInfo):
-            o._fill()
-        return super().__eq__(o)
 
-    def __ne__(self, o): return not self.__eq__(o)
-    __hash__ = None
-    def get(self, k, d=None): self._fill(); return super().get(k, d)
-    def keys(self): self._fill(); return super().keys()
-    def values(self): self._fill(); return super().values()
-    def items(self): self._fill(); return super().items()
-    def copy(self): self._fill(); return dict(self)
+class LazyScalar:
+    """One info value of an update that may not have run yet - what a JAX device scalar is in the reference's info dict (agents/fql.py:39-44;
+    main.py:276 reads them at log time).  float(x), arithmetic, comparisons, formatting, numpy conversion all block until the update has run and
+    then behave as the plain float.  Pickles as a float."""
+    __slots__ = ('_p', '_i')
+
+    def __init__(self, pending, i):
+        self._p, self._i = pending, i
+
+    def __float__(self): return self._p.get()[self._i]
+    def item(self): return float(self)
+    def __int__(self): return int(float(self))
+    def __bool__(self): return bool(float(self))
+    def __round__(self, n=None): return round(float(self), n)
+    def __repr__(self): return repr(float(self))
+    __str__ = __repr__
+    def __format__(self, spec): return format(float(self), spec)
+    def __array__(self, dtype=None, copy=None): return np.asarray(float(self), dtype=dtype)
+    def __reduce__(self): return (float, (float(self),))
+    def __hash__(self): return hash(float(self))
+    def __eq__(self, o): return float(self) == o
+    def __ne__(self, o): return float(self) != o
+    def __lt__(self, o): return float(self) < o
+    def __le__(self, o): return float(self) <= o
+    def __gt__(self, o): return float(self) > o
+    def __ge__(self, o): return float(self) >= o
+    def __neg__(self): return -float(self)
+    def __pos__(self): return float(self)
+    def __abs__(self): return abs(float(self))
+    def __add__(self, o): return float(self) + o
+    def __radd__(self, o): return o + float(self)
+    def __sub__(self, o): return float(self) - o
+    def __rsub__(self, o): return o - float(self)
+    def __mul__(self, o): return float(self) * o
+    def __rmul__(self, o): return o * float(self)
+    def __truediv__(self, o): return float(self) / o
+    def __rtruediv__(self, o): return o / float(self)
+    def __pow__(self, o): return float(self) ** o
+    def __rpow__(self, o): return o ** float(self)
+
+
+class LazyInfo(dict):
+    """What `update` returns as `info` (the reference returns device scalars nobody waits for until main.py:276 logs them, so its training loop
+    never synchronises per step): a REAL dict holding the 13 keys from the start - len(), iteration, json / pickle see all of them - whose values
+    are LazyScalar objects that block on first use.  `to_dict()` gives plain floats (json.dumps(info.to_dict()), or json.dumps(info,
+    default=float)); pickling and copy() give a plain dict of floats.  Holding it across more than 64 later lazy updates without reading it
+    raises on first use (the engine keeps 64 snapshots)."""
+
+    def __init__(self, agent, ticket):
+        p = _Pending(agent, ticket)
+        super().__init__((k, LazyScalar(p, i)) for i, k in enumerate(INFO_KEYS))
+
+    def to_dict(self):
+        return {k: float(v) for k, v in self.items()}
+
+    def copy(self):
+        return self.to_dict()
+
+    def __reduce__(self):
+        return (dict, (self.to_dict(),))
 
 
 class FQLAgent:
@@ -274,6 +314,36 @@ class FQLAgent:
         self._check(self._lib.fql_info_enqueue(self._h, stream, C.byref(t)))
         return LazyInfo(self, int(t.value))
 
+    def _resident_noise(self, noise, B, stream):
+        """(fql_noise or None, keep-alive) for the device-resident update paths: explicit tensors, else - with config['rng'] = 'jax' /
+        'jax_partitionable' - the reference's key derivation advanced on the host and the five tensors generated on the device from the derived
+        keys (exactly what update() does), else None = the engine's Philox stream."""
+        nz, nargs = self._noise_args(noise, B)
+        jax_mode = self._jax_mode()
+        if noise is None and jax_mode is not None:
+            self.rng, keys = jax_prng.fql_update_keys(self.rng, partitionable=jax_mode)
+            nz = self._device_noise(keys, jax_mode, B, stream)
+        return nz, nargs
+
+    def _host_idx(self, idxs, n, rows, what):
+        """int64 view of HOST gather indices, checked against the rows the device array holds: an index >= size would train on zero rows or read
+        past the array on the device.  Device tensors are passed through unchecked (documented in INTEGRATION.md)."""
+        if hasattr(idxs, 'data_ptr'):
+            keep = idxs.long().contiguous()
+            if keep.numel() != n:
+                raise ValueError(f'{what} must have {n} entries')
+            if not keep.is_cuda:
+                lo, hi = (int(keep.min()), int(keep.max())) if n else (0, -1)
+                if lo < 0 or hi >= rows:
+                    raise ValueError(f'{what} out of range: [{lo}, {hi}] for {rows} rows')
+            return keep, keep.data_ptr()
+        keep = np.ascontiguousarray(idxs, dtype=np.int64)
+        if keep.size != n:
+            raise ValueError(f'{what} must have {n} entries')
+        if n and (keep.min() < 0 or keep.max() >= rows):
+            raise ValueError(f'{what} out of range: [{int(keep.min())}, {int(keep.max())}] for {rows} rows')
+        return keep, keep.ctypes.data
+
     def read_info(self) -> Dict[str, float]:
         """The 13 info scalars of the last update (blocks until that update has run)."""
         buf = (C.c_float * _cabi.FQL_NUM_INFO)()
@@ -404,14 +474,13 @@ class FQLAgent:
         `idxs` = (dataset_idxs, replay_idxs), B // 2 each, or None (engine RNG)."""
         B = int(batch_size or self.config['batch_size'])
         self._ensure_batch(B)
-        nz, nargs = self._noise_args(noise, B)
+        nz, nargs = self._resident_noise(noise, B, stream)
         ia = ib = None
         keep = None
         if idxs is not None:
-            ka = np.ascontiguousarray(idxs[0], dtype=np.int64); kb = np.ascontiguousarray(idxs[1], dtype=np.int64)
-            if ka.size != B // 2 or kb.size != B // 2:
-                raise ValueError('idxs must be two arrays of batch_size // 2 entries')
-            ia, ib, keep = ka.ctypes.data, kb.ctypes.data, (ka, kb)
+            ka, ia = self._host_idx(idxs[0], B // 2, self.dataset_size()[0], 'dataset idxs')
+            kb, ib = self._host_idx(idxs[1], B // 2, self.replay_size()[0], 'replay idxs')
+            keep = (ka, kb)
         cp = None
         if crop_froms is not None:
             ck = np.ascontiguousarray(crop_froms, dtype=np.int32)
@@ -433,15 +502,10 @@ class FQLAgent:
         `crop_froms` int [B, 2] fixes the random-crop offsets Dataset.augment would draw (None: engine RNG with p_aug)."""
         B = int(batch_size or self.config['batch_size'])
         self._ensure_batch(B)
-        nz, nargs = self._noise_args(noise, B)
+        nz, nargs = self._resident_noise(noise, B, stream)
         ip, keep = None, None
         if idxs is not None:
-            if hasattr(idxs, 'data_ptr'):
-                keep = idxs.long().contiguous(); ip = keep.data_ptr()
-            else:
-                keep = np.ascontiguousarray(idxs, dtype=np.int64); ip = keep.ctypes.data
-            if (keep.numel() if hasattr(keep, 'numel') else keep.size) != B:
-                raise ValueError('idxs must have batch_size entries')
+            keep, ip = self._host_idx(idxs, B, self.dataset_size()[0], 'idxs')
         if crop_froms is not None:
             ck = np.ascontiguousarray(crop_froms, dtype=np.int32)
             if ck.shape != (B, 2):
@@ -460,17 +524,17 @@ class FQLAgent:
         if batch is not None:
             B, args = self._batch_args(batch)
             self._ensure_batch(B)
-            nz, nargs = self._noise_args(noise, B)
-            st = stream if stream is not None else self._stream(args + nargs)
+            st = stream if stream is not None else self._stream(args)
+            nz, nargs = self._resident_noise(noise, B, st)
             self._check(self._lib.fql_update_begin(self._h, *[a.ptr for a in args], B, C.byref(nz) if nz else None, st))
             self._keep = (args, nargs)
         else:
             B = int(batch_size or self.config['batch_size'])
             self._ensure_batch(B)
-            nz, nargs = self._noise_args(noise, B)
+            nz, nargs = self._resident_noise(noise, B, stream)
             ip, keep = None, None
             if idxs is not None:
-                keep = np.ascontiguousarray(idxs, dtype=np.int64); ip = keep.ctypes.data
+                keep, ip = self._host_idx(idxs, B, self.dataset_size()[0], 'idxs')
             self._check(self._lib.fql_update_from_dataset_begin(self._h, ip, B, int(shard[0]), int(shard[1]),
                                                                 C.byref(nz) if nz else None, stream))
             self._keep = (keep, nargs)
@@ -495,17 +559,17 @@ class FQLAgent:
         if batch is not None:
             B, args = self._batch_args(batch)
             self._ensure_batch(B)
-            nz, nargs = self._noise_args(noise, B)
+            nz, nargs = self._resident_noise(noise, B, stream0)
             self._check(self._lib.fql_update_begin_split(self._h, *[a.ptr for a in args], B, C.byref(nz) if nz else None,
                                                          stream0, stream1))
             self._keep = (args, nargs)
         else:
             B = int(batch_size or self.config['batch_size'])
             self._ensure_batch(B)
-            nz, nargs = self._noise_args(noise, B)
+            nz, nargs = self._resident_noise(noise, B, stream0)
             ip, keep = None, None
             if idxs is not None:
-                keep = np.ascontiguousarray(idxs, dtype=np.int64); ip = keep.ctypes.data
+                keep, ip = self._host_idx(idxs, B, self.dataset_size()[0], 'idxs')
             self._check(self._lib.fql_update_from_dataset_begin_split(self._h, ip, B, int(shard[0]), int(shard[1]),
                                                                       C.byref(nz) if nz else None, stream0, stream1))
             self._keep = (keep, nargs)

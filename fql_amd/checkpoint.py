@@ -110,16 +110,20 @@ def to_state_dict(agent, visual_layout: str = 'nested') -> dict:
     """flax.serialization.to_state_dict(agent) for the engine-backed FQLAgent.
 
     visual_layout (visual agents only): 'nested' = modules_actor_bc_flow/encoder (default), 'toplevel' = also a
-    top-level modules_actor_bc_flow_encoder holding the same (shared) arrays."""
+    top-level modules_actor_bc_flow_encoder holding the same (shared) arrays, 'toplevel-only' = the encoder ONLY under
+    modules_actor_bc_flow_encoder (no nested copy) - the layout flax is likely to produce, since ModuleDict adopts the shared encoder
+    instance first (agents/fql.py:230-232); use it to export to the JAX reference (unverified: no reference checkpoint exists here)."""
     opt = agent.get_opt_state()
     rng = np.asarray(getattr(agent, 'rng', [(agent._seed >> 32) & 0xFFFFFFFF, agent._seed & 0xFFFFFFFF]), dtype=np.uint32)
     trees = [agent.get_params(), opt['mu'], opt['nu']]
-    if visual_layout == 'toplevel':
+    if visual_layout in ('toplevel', 'toplevel-only'):
         for t in trees:
             if isinstance(t.get(BC_MOD), dict) and 'encoder' in t[BC_MOD]:
                 t[BC_ENC_TOP] = t[BC_MOD]['encoder']
+                if visual_layout == 'toplevel-only':
+                    t[BC_MOD] = {k: v for k, v in t[BC_MOD].items() if k != 'encoder'}
     elif visual_layout != 'nested':
-        raise ValueError("visual_layout must be 'nested' or 'toplevel'")
+        raise ValueError("visual_layout must be 'nested', 'toplevel' or 'toplevel-only'")
     return {
         'rng': rng,
         'network': {

@@ -158,3 +158,18 @@ def test_toplevel_export_layout():
     a = FakeAgent(O.init_params(0, (32, 32, 3), 2, cfg))
     st = checkpoint.to_state_dict(a, visual_layout='toplevel')
     assert checkpoint.BC_ENC_TOP in st['network']['params'] and checkpoint.BC_ENC_TOP in st['network']['opt_state']['0']['mu']
+
+
+def test_toplevel_only_export_round_trips():
+    """'toplevel-only': the shared encoder ONLY under modules_actor_bc_flow_encoder (the layout flax is likely to write: ModuleDict adopts the
+    shared instance first, agents/fql.py:230-232).  It must restore into the engine's tree unchanged."""
+    cfg = _small_cfg(encoder='impala_small')
+    a = FakeAgent(O.init_params(0, (32, 32, 3), 2, cfg))
+    st = checkpoint.to_state_dict(a, visual_layout='toplevel-only')
+    for tree in (st['network']['params'], st['network']['opt_state']['0']['mu'], st['network']['opt_state']['0']['nu']):
+        assert checkpoint.BC_ENC_TOP in tree and 'encoder' not in tree[checkpoint.BC_MOD]
+    b = FakeAgent(O.init_params(1, (32, 32, 3), 2, cfg))
+    rep = checkpoint.from_state_dict(b, st)
+    assert rep['visual_layout'] == 'toplevel' and not rep['missing']
+    for (p, x), (_, y) in zip(O.tree_leaves_with_path(a.get_params()), O.tree_leaves_with_path(b.get_params())):
+        np.testing.assert_array_equal(x, y, err_msg=p)
