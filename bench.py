@@ -37,13 +37,14 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
+PMC_FILE, PMC_FILE_BF16X3 = 'r03_pmc_summary.json', 'r03_pmc_summary_bf16x3.json'   # committed rocprofv3 --pmc summaries (tools/profile.sh)
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (matrix), v_mfma_f32_16x16x4_f32
 BF16_MATRIX_PEAK_TFLOPS = 2516.6  # dense bf16 matrix peak; a bf16x3 product is three bf16 MFMAs: peak / 3 = 838.9 algorithmic TFLOP/s
 OP_NAMES = ['fql_gemm16_kernel', 'fql_side_kernel', 'fql_wgrad_kernel', 'fql_lnbwd_kernel', 'fql_prep_kernel', 'fql_post_onestep_kernel',
             'fql_euler_finish_kernel', 'fql_euler_persistent_kernel', 'fql_loss_critic_kernel', 'fql_loss_q_kernel', 'fql_loss_bc_kernel',
             'fql_loss_actor_kernel', 'fql_conv_wprep_kernel', 'fql_conv3x3_kernel', 'fql_conv3x3_u8_kernel', 'fql_maxpool_kernel',
             'fql_maxpool_bwd_kernel', 'fql_conv_wgrad_kernel', 'fql_conv_wgrad_reduce_kernel', 'fql_enc_dz_kernel', 'fql_chain_kernel',
-            'fql_wfrag_kernel', 'fql_adam_kernel', 'fql_finalize_kernel']
+            'fql_wfrag_kernel', 'fql_xchain_kernel', 'fql_adam_kernel', 'fql_finalize_kernel']
 
 
 def cpu_baseline(cfg, od, ad, B, budget_s=18.0, img=None):
@@ -135,6 +136,76 @@ def profile_kernels(agent, B, reps, split=False):
     return out
 
 
+def pmc_counters(fname, kernel):
+    """Static rocprofv3 --pmc numbers of `kernel` from a committed summary (collected in separate passes, tools/profile.sh): returned with the
+    hash of the kernel sources they were measured on and `traffic_stale` = the sources here differ from those."""
+    path = os.path.join(ROOT, 'profiles', fname)
+    if not os.path.exists(path):
+        return {}
+    try:
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        from pmc_summary import source_sha16
+        pj = json.load(open(path))
+        k = pj.get('kernels', {}).get(kernel)
+        if not k:
+            return {}
+        return {'traffic': k.get('hbm_bytes_per_launch'), 'mfma_util': k.get('mfma_util'), 'traffic_source': pj.get('source'),
+                'traffic_file': 'profiles/' + fname, 'traffic_source_sha16': pj.get('source_sha16'),
+                'traffic_stale': pj.get('source_sha16') != source_sha16(ROOT)}
+    except Exception:
+        return {}
+
+
+def short_window(agent, B, steps, warmup, torch):
+    for _ in range(warmup):
+        agent.update_from_dataset(B)
+    torch.cuda.synchronize(); agent.read_info()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        agent.update_from_dataset(B)
+    agent.read_info(); torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def other_configs(torch, peak_tf):
+    """The other single-GPU configurations of BASELINE.json in the same process, short fenced windows: configs[2] (obs 40, act 4, B 1024, alpha 300) and
+    configs[4] (visual: impala_small, 64x64x9, B 256, alpha 300).  fp32.  Each: rate, ms per update, its dominant kernel against the fp32 matrix peak."""
+    import fql_amd
+    from fql_amd.synthetic import make_synthetic_dataset, make_synthetic_frames
+    res = []
+    for name in ('configs[2]', 'configs[4]'):
+        cfg = fql_amd.get_config()
+        if name == 'configs[2]':
+            od, ad, B, steps, warm = 40, 4, 1024, 200, 20
+            cfg.update(alpha=300.0, batch_size=B)
+            ds = make_synthetic_dataset(200_000, od, ad, seed=0)
+            agent = fql_amd.FQLAgent.create(0, ds['observations'][:1], ds['actions'][:1], cfg)
+            agent.upload_dataset(ds)
+            work = 'synthetic replay (obs=40, act=4), batch=1024, hidden=512x4, flow_steps=10, alpha=300, 200k device-resident transitions (BASELINE.json configs[2])'
+        else:
+            ad, B, steps, warm = 5, 256, 60, 10
+            cfg.update(alpha=300.0, batch_size=B, encoder='impala_small')
+            ds = make_synthetic_frames(4000, ad, seed=0)
+            agent = fql_amd.FQLAgent.create(0, np.zeros((1, 64, 64, 9), np.uint8), ds['actions'][:1], cfg)
+            agent.upload_dataset(ds, frame_stack=3, p_aug=0.5)
+            work = 'visual-cube-shaped synthetic replay (uint8 64x64x9, act=5), impala_small encoders, batch=256, alpha=300, p_aug=0.5, 4000 device-resident frames (BASELINE.json configs[4])'
+        dt = short_window(agent, B, steps, warm, torch)
+        st = agent.stats()
+        r = {'workload': work, 'value': round(steps / dt, 2), 'unit': 'grad-steps/s', 'ms_per_step': round(dt * 1e3 / steps, 4), 'steps': steps, 'warmup': warm,
+             'dtype': 'f32', 'samples_per_s': round(steps / dt * B, 1), 'kernel_launches_per_update': st['launches_per_update'],
+             'whole_update_tflops': round(2.0 * st['macs_per_update'] * steps / dt / 1e12, 3)}
+        fams = profile_kernels(agent, B, reps=5)
+        if fams:
+            mm = {k: v for k, v in fams.items() if v['flop_per_launch'] > 0}
+            dom = max(mm, key=lambda k: mm[k]['us_per_update'])
+            ach = mm[dom]['flop_per_launch'] / (mm[dom]['avg_us'] * 1e-6) / 1e12
+            r['roofline'] = {'kernel': dom, 'achieved': round(ach, 3), 'peak': peak_tf, 'unit': 'TFLOP/s', 'frac': round(ach / peak_tf, 4),
+                             'avg_launch_us': round(mm[dom]['avg_us'], 3), 'launches_per_update': round(mm[dom]['launches_per_update'], 2)}
+        agent.close()
+        res.append(r)
+    return res
+
+
 def bench_bf16x3(args, cfg, ds, od, ad, B, torch):
     """Second agent, precision='bf16x3', same workload / steps / warm-up / fences as the headline; never the headline `value`."""
     import fql_amd
@@ -143,7 +214,7 @@ def bench_bf16x3(args, cfg, ds, od, ad, B, torch):
     c2['precision'] = 'bf16x3'
     agent = fql_amd.FQLAgent.create(0, ds['observations'][:1], ds['actions'][:1], c2)
     agent.upload_dataset(ds)
-    warm = max(args.warmup, 50)   # (a freshly created second agent: its first graph launches are not what this block reports)
+    warm = args.warmup   # (the headline's own warm-up: the two rates in one line are like for like)
     for _ in range(warm):
         agent.update_from_dataset(B)
     torch.cuda.synchronize(); agent.read_info()
@@ -172,17 +243,9 @@ def bench_bf16x3(args, cfg, ds, od, ad, B, torch):
                            'traffic': None, 'kernel': dom, 'flop_per_launch': round(d['flop_per_launch']), 'avg_launch_us': round(d['avg_us'], 3),
                            'launches_per_update': round(d['launches_per_update'], 2),
                            'peak_note': 'dense bf16 matrix peak 2516.6 TFLOP/s / 3 MFMAs per product; the kernel is latency-bound, not MFMA-bound'}
-        pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_summary_bf16x3.json')
-        if os.path.exists(pmc):
-            try:
-                pj = json.load(open(pmc))
-                k = pj.get('kernels', {}).get('fql_side_split_kernel')
-                if k:
-                    res['roofline']['traffic'] = k.get('hbm_bytes_per_launch')
-                    res['roofline']['mfma_util'] = k.get('mfma_util')
-                    res['roofline']['traffic_source'] = pj.get('source')
-            except Exception:
-                pass
+        res['roofline'].update(pmc_counters(PMC_FILE_BF16X3, dom))
+        if res['roofline'].get('traffic'):
+            res['roofline']['hbm_gbps'] = round(res['roofline']['traffic'] / (d['avg_us'] * 1e-6) / 1e9, 1)
         res['kernels'] = {k: {'launches': round(v['launches_per_update'], 2), 'avg_us': round(v['avg_us'], 2), 'share': round(v['share'], 4)}
                           for k, v in sorted(fams.items(), key=lambda kv: -kv[1]['us_per_update'])}
     if not args.no_cpu_baseline:
@@ -367,17 +430,10 @@ def main():
                         'measured': 'start / stop HIP events attached to every dispatch (hipExtLaunchKernelGGL) of 20 updates issued in program '
                                     'order on the engine stream (fql_profile_update; serialised like rocprofv3 --kernel-trace): avg_launch_us = mean '
                                     'elapsed time of the pair = the dispatch duration a kernel trace reports'}
-                pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_summary.json')
-                if os.path.exists(pmc) and not visual:
-                    try:
-                        pj = json.load(open(pmc))
-                        k = pj.get('kernels', {}).get(dom)
-                        if k:
-                            roof['traffic'] = k.get('hbm_bytes_per_launch')
-                            roof['mfma_util'] = k.get('mfma_util')
-                            roof['traffic_source'] = pj.get('source')
-                    except Exception:
-                        pass
+                if not visual:
+                    roof.update(pmc_counters(PMC_FILE if args.precision == 'fp32' else PMC_FILE_BF16X3, dom))
+                    if roof.get('traffic'):   # HBM-side bytes per launch (rocprofv3 --pmc, separate passes) over the launch duration measured here
+                        roof['hbm_gbps'] = round(roof['traffic'] / (d['avg_us'] * 1e-6) / 1e9, 1)
                 out['kernels'] = {k: {'launches': round(v['launches_per_update'], 2), 'avg_us': round(v['avg_us'], 2),
                                       'share': round(v['share'], 4),
                                       'tflops': round(v['flop_per_launch'] / (v['avg_us'] * 1e-6) / 1e12, 2) if v['flop_per_launch'] else None}
@@ -399,6 +455,8 @@ def main():
         out['roofline'] = roof
         if world == 1 and not args.no_extras and not visual and args.precision == 'fp32' and not force_dp:
             out['precision_bf16x3'] = bench_bf16x3(args, cfg, ds, od, ad, B, torch)
+            if (od, ad, B) == (29, 8, 256):
+                out['other_configs'] = other_configs(torch, FP32_MATRIX_PEAK_TFLOPS)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, od, ad, B, img=(64, 64, 9) if visual else None)
             if not visual:

@@ -15,10 +15,20 @@ v_mfma_f32_16x16x4_f32 holds its SIMD's matrix pipe for 32 cycles, so the counte
 """
 import csv
 import glob
+import hashlib
 import json
+import os
 import re
 import sys
 from collections import defaultdict
+
+
+def source_sha16(root):
+    """Hash of the kernel sources the counters were measured on: bench.py recomputes it and marks the counters stale when the sources changed."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, 'fql_amd', 'csrc', '*'))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def base(name):
@@ -62,7 +72,8 @@ def main():
             if c in m:
                 d[c.lower()] = round(m[c])
         kernels[k] = d
-    json.dump({'source': label, 'kernels': kernels}, open(out, 'w'), indent=1)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    json.dump({'source': label, 'source_sha16': source_sha16(repo), 'kernels': kernels}, open(out, 'w'), indent=1)
     for k, d in kernels.items():
         print(k, d)
 

@@ -2,7 +2,7 @@
 # Round profile set (run through gpurun from the repo root): kernel trace + stats, then the PMC passes, each in its own run
 # (no trace domains beside --pmc).  usage: tools/profile.sh <tag, e.g. r02>   -> gpurun_out/<tag>_prof/...
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
