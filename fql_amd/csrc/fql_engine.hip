@@ -166,8 +166,6 @@ struct Launch {
     void* table = nullptr;  // device task table (GEMM/WGRAD/LNBWD)
     Op op;                  // arg-struct kernels
     bool pool_fused = false; // OP_CONV_U8: the stack's max-pool runs inside the convolution kernel (fql_conv3x3_pool_kernel)
-    ChainArgs chain2{};     // OP_CHAIN variant E: second task of the launch (the other ensemble member)
-    bool chain_pair = false;
     int lane = 0;
     bool tmt2 = false, kbig = false, euler = false;
     double macs = 0.0;           // algorithmic multiply-accumulates of the GEMM-shaped tasks of this launch (roofline accounting)
@@ -188,10 +186,6 @@ struct Program {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     int64_t macs = 0;
-    // segment graphs (run_segments): maximal runs of one lane's launches without a cross-lane wait inside or a cross-lane reader in front of the end,
-    // each captured as its own LINEAR graph; first launch index, lane, member launches
-    struct Seg { int lane = 0; std::vector<int> idx; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
-    std::vector<Seg> segs;
     // threaded eager issue (run_threaded): sequence number of the run whose event record of launch i has been enqueued
     std::unique_ptr<std::atomic<uint64_t>[]> rec;
     size_t rec_n = 0;
@@ -456,8 +450,8 @@ struct fql_engine {
     // Measured (visual update, one box): the uint8 layer fused +2.8 % (fp32) and more in bf16x3; the float layers of stacks 1 / 2 fused too: bf16x3 370.5 -> 373.9, fp32
     // 311.7 -> 308.3 (their 5-row tiles redo a quarter of the rows, which fp32 MFMAs pay for) - so those are fused under precision = 2 only (FQL_FUSE_POOL_FLOAT=0/1 overrides).
     bool pool_fusable(const EncStack& st, const ConvL& c, bool first_stack) const {
-        static const bool on = getenv("FQL_NO_FUSE_POOL") == nullptr;
-        static const int float_env = getenv("FQL_FUSE_POOL_FLOAT") ? atoi(getenv("FQL_FUSE_POOL_FLOAT")) : -1;
+        constexpr bool on = true;
+        constexpr int float_env = -1;
         const bool on_float = float_env >= 0 ? float_env != 0 : cfg.precision == 2;
         const int Ci = pad16c(c.cin);
         if (!on || st.W % 16 || st.W < 16 || st.W > 128 || st.H % 2 || (c.cout != 16 && c.cout != 32)) return false;
@@ -496,7 +490,7 @@ struct fql_engine {
         const Net& n = nets[NET_BC];
         const int nh = n.nl() - 1;
         const int H = n.layers[0].out_p;
-        bool ok = getenv("FQL_NO_CHAIN") == nullptr && !cfg.actor_layer_norm && cfg.act_dim <= 15 && nh >= 3 && (H == 256 || H == 512);
+        bool ok = !cfg.actor_layer_norm && cfg.act_dim <= 15 && nh >= 3 && (H == 256 || H == 512);
         for (int l = 0; l < nh && ok; ++l) ok = n.layers[l].out == H && n.layers[l].out_p == H;
         use_chain = ok;
         if (!ok) return;
@@ -852,7 +846,7 @@ struct fql_engine {
         if (in_mode == 2 && (a.Ci != 16 || a.Co != 16)) invalid("uint8 convolution weight gradient: <= 16 input channels and 16 output channels expected (got %d -> %d)", c.cin, c.cout);
         a.R = conv_rows(H, W, a.Ci, a.Co, true);
         a.nblocks = n * (H / a.R);
-        static const int cwg_env = getenv("FQL_CWG_GRID") ? atoi(getenv("FQL_CWG_GRID")) : 256;   // persistent workgroups per weight-gradient task
+        constexpr int cwg_env = 256;   // persistent workgroups per weight-gradient task
         op.cw_grid = std::min(a.nblocks, cwg_env);
         op.reads = {in_id, dout_id};
         op.writes = {wp};
@@ -961,7 +955,7 @@ struct fql_engine {
 
     // throughput-lane tasks with 64-aligned shapes go to the 64x64 LDS-tiled kernel
     bool want64(int M, int N, int K, int flags) const {
-        static const bool off = getenv("FQL_NO_GEMM64") != nullptr;
+        constexpr bool off = false;
         if (off || emit_lane == 0 || !allow64) return false;
         if (M % 64 || N % 64 || K % 64) return false;
         if (flags & (GF_EULER | GF_CLIP_OUT)) return false;
@@ -1176,7 +1170,7 @@ struct fql_engine {
                 a.M = B; a.ad = ad; a.ap = ap;
                 a.inv_steps = 1.0f / (float)fs; a.t_s = (float)s / (float)fs;
                 a.variant = 1;
-                static const int chain_prio = getenv("FQL_CHAIN_PRIO") ? atoi(getenv("FQL_CHAIN_PRIO")) : 0;
+                constexpr int chain_prio = 0;
                 a.prio = chain_prio;
                 op.reads = {a.Wf, P + ly.w};
                 if (l == 1) {
@@ -1280,44 +1274,6 @@ struct fql_engine {
         const Net& n = nets[p.net];
         const int L = n.nl() - 1;
         auto rows = [&](float* base, int ld) { return base + (size_t)row_off * ld; };
-        // Input-gradient-only pass through a LayerNorm'd MLP with a scalar head (the critic under the actor's Q term): every level
-        // (LayerNorm backward + dgrad) as ONE chain-kernel launch (variant E), the two ensemble members paired in a launch - 4 launches
-        // instead of 8 on the lane the one-step actor's tail waits for.  Built, parity-green and MEASURED SLOWER (bf16x3 3035 -> 2880,
-        // fp32 2580 -> 2546 updates/s: the 16 column-tile workgroups of a row tile each reload three [16 x H] operands and redo the row
-        // statistics), so it is opt-in: FQL_CHAIN_LN=1.
-        static const bool chain_ln = getenv("FQL_CHAIN_LN") != nullptr && atoi(getenv("FQL_CHAIN_LN")) != 0;
-        bool fuse_ln = chain_ln && !param_grads && input_grad && !visual && L >= 2 && n.layers[L].out == 1 && M % 16 == 0;
-        const int Hc = n.layers[0].out_p;
-        fuse_ln = fuse_ln && (Hc == 256 || Hc == 512) && n.layers[0].in_p % 32 == 0;
-        for (int l = 0; l < L && fuse_ln; ++l) fuse_ln = n.layers[l].ln && n.layers[l].out_p == Hc && (l == 0 || n.layers[l].in_p == Hc);
-        if (fuse_ln) {
-            for (int l = L - 1; l >= 0; --l) {
-                const Layer& ly = n.layers[l];
-                Op co{};
-                co.type = OP_CHAIN;
-                ChainArgs& a = co.chain;
-                a.variant = 4; a.hw = Hc; a.M = M;
-                if (l == L - 1) {
-                    const Layer& head = n.layers[L];
-                    a.A = nullptr; a.dq = p.dz[L]; a.ldq = head.out_p; a.wq = P + head.w; a.ldw = head.out_p;
-                    co.reads = {p.dz[L], a.wq};
-                } else {
-                    a.A = p.dy[l];
-                    co.reads = {p.dy[l]};
-                }
-                a.Zprev = rows(p.z[l], ly.out_p); a.Gv = rows(p.g[l], ly.out_p); a.stats = p.stats[l] + (size_t)row_off * 2; a.gamma = P + ly.g;
-                a.width = ly.out;
-                a.Wf = P + ly.w;
-                a.ncol = ly.in_p; a.ldc = ly.in_p;
-                a.C = (l == 0) ? p.dx0 : p.dy[l - 1];
-                for (const void* r : {(const void*)p.z[l], (const void*)p.g[l], (const void*)p.stats[l], (const void*)a.gamma, (const void*)a.Wf}) co.reads.push_back(r);
-                co.writes = {a.C};
-                push(pr, co);
-            }
-            if (align_with)
-                for (size_t i = first_op; i < pr.ops.size(); ++i) { pr.ops[i].reads.push_back(align_with); break; }
-            return;
-        }
         for (int l = L; l >= 0; --l) {
             const Layer& ly = n.layers[l];
             float* dz = p.dz[l];
@@ -1338,9 +1294,9 @@ struct fql_engine {
                 // weight gradients feed nothing but the optimizer: those of a chain that runs on the critical lane are
                 // issued on the side lane so they never sit between two links of that chain
                 const int keep = emit_lane;
-                static const bool wlane = getenv("FQL_WLANE") != nullptr;  // (a separate wgrad lane is worse than sharing launches)
+                constexpr bool wlane = false;  // (a separate wgrad lane is worse than sharing launches)
                 if (wlane) emit_lane = 2;
-                else if (emit_lane == 0 && !split_build && getenv("FQL_NO_WSIDE") == nullptr) emit_lane = 1;
+                else if (emit_lane == 0 && !split_build) emit_lane = 1;
                 if (defer_wgrads) { op.lane = emit_lane; defer_wgrads->push_back(op); }
                 else push(pr, op);
                 emit_lane = keep;
@@ -1415,7 +1371,7 @@ struct fql_engine {
                 if (want64(t.M, t.N, t.K, t.flags)) op.type = OP_GEMM64;
                 // a square hidden layer on the latency lane (the one-step actor's backward tail behind the Euler chain): the chain
                 // kernel's variant D does it in about half the time of the generic 16-row kernel
-                static const bool chain_dgrad = getenv("FQL_NO_CHAIN_DGRAD") == nullptr;
+                constexpr bool chain_dgrad = true;
                 if (chain_dgrad && op.type == OP_GEMM && use_chain && t.N == t.K && t.N == cfg.actor_hidden[0] && t.M % 16 == 0 &&
                     t.lda == t.K && t.ldb == t.K && t.ldc == t.N && prev.out_p == t.N) {
                     Op co{};
@@ -1470,8 +1426,6 @@ struct fql_engine {
         int maxlv = 0;
         for (const Op& op : pr.ops) maxlv = std::max(maxlv, op.level);
         pr.launches.clear();
-        for (Program::Seg& sg : pr.segs) { if (sg.exec) hipGraphExecDestroy(sg.exec); if (sg.graph) hipGraphDestroy(sg.graph); }
-        pr.segs.clear();
         pr.rec_n = 0;
         pr.two_lanes = false;
         for (bool& b : pr.lane_used) b = false;
@@ -1484,7 +1438,7 @@ struct fql_engine {
                     const Op& op = pr.ops[oi];
                     if (op.level == lv && op.type == ty && op.lane == lane) sel.push_back(&op);
                 }
-                static const bool merge_side = getenv("FQL_NO_SIDE") == nullptr;
+                constexpr bool merge_side = true;
                 if (merge_side && (ty == OP_WGRAD || ty == OP_LNBWD || ty == OP_POSTOS || ty == OP_LOSS_CRITIC || ty == OP_LOSS_Q ||
                                    ty == OP_LOSS_BC)) continue;  // folded into the OP_GEMM64 iteration
                 if (merge_side && ty == OP_GEMM64) {
@@ -1509,14 +1463,14 @@ struct fql_engine {
                     for (const Op* o : selm) launch_of[o - pr.ops.data()] = li;
                     // 32 x 64 tiles while a level is a latency chain (B = 256: 1.5 workgroups per CU), 64 x 64 once a task alone
                     // brings >= 128 of them (M >= 1024: +2 % at B = 1024)
-                    static const int ri_env = getenv("FQL_G64_RI") ? atoi(getenv("FQL_G64_RI")) : 0;
-                    static const bool xcd_order = getenv("FQL_NO_XCD") == nullptr;
+                    constexpr int ri_env = 0;
+                    constexpr bool xcd_order = true;
                     int ri = 1;
                     int tile = 0;
                     std::vector<GemmTask> tg;
                     // tile shape of the 32-row tasks of this launch: 32 x 64 unless 32 x 32 tiles deal out more evenly over the CUs
                     // (e.g. 384 tiles of 32 x 64 = two tile times on half the CUs; 768 of 32 x 32 = three half-size tiles everywhere)
-                    static const int nj_env = getenv("FQL_TILE_NJ") ? atoi(getenv("FQL_TILE_NJ")) : 0;
+                    constexpr int nj_env = 0;
                     int nj = 2;
                     {
                         int t64 = 0;
@@ -1548,7 +1502,7 @@ struct fql_engine {
                             const int ntm = t.M / 32;
                             // gm row groups x gn column groups: an A row panel is fetched by gn XCDs, a B column panel by gm -> fewest panel bytes
                             // (FQL_XCD_GM forces gm; measured on the whole update: the rule's choice 3075, forced 4: 3001-3061, 8: 2864-3026, 1: 2967-3040, off: 3025)
-                            static const int gm_env = getenv("FQL_XCD_GM") ? atoi(getenv("FQL_XCD_GM")) : 0;
+                            constexpr int gm_env = 0;
                             double best = 1e30;
                             for (int gm : {1, 2, 4, 8}) {
                                 const int gn = 8 / gm;
@@ -1633,13 +1587,13 @@ struct fql_engine {
                         // persistent uint8 kernel: its 162 registers (launch bound 3 waves per SIMD) allow three workgroups per CU; exactly that many are launched (a fourth
                         // round of workgroups would run alone) and dealt to the tasks in proportion to their row blocks (the one-step pass
                         // holds [obs ; next_obs], twice the images of the others), rounded DOWN so the total never exceeds the resident set
-                        static const int u8_per_cu = getenv("FQL_U8_WGS_PER_CU") ? atoi(getenv("FQL_U8_WGS_PER_CU")) : 3;
+                        constexpr int u8_per_cu = 3;
                         for (const Op* o : sel) {
                             ConvArgs a = o->conv;
                             const int nb = a.N * (a.H / a.R);
                             a.tile0 = tile;
                             // float layers: a workgroup per row block by default; FQL_CONV_WGS_PER_CU=k makes them persistent too (measured: +-1 %)
-                            static const int conv_per_cu = getenv("FQL_CONV_WGS_PER_CU") ? atoi(getenv("FQL_CONV_WGS_PER_CU")) : 0;
+                            constexpr int conv_per_cu = 0;
                             const int per_cu = ty == OP_CONV_U8 ? u8_per_cu : conv_per_cu;
                             a.nwg = per_cu > 0 ? std::min(nb, std::max(1, (int)(((long long)per_cu * num_cus * nb) / nb_all))) : nb;
                             if (a.parg) {   // convolution + max-pool in one kernel: a workgroup per (image, pooled row pair)
@@ -1678,18 +1632,7 @@ struct fql_engine {
                     continue;
                 }
                 if (!is_table((OpType)ty)) {
-                    const Op* pending = nullptr;   // an OP_CHAIN variant-E op waiting for a partner of the same shape (fql_chain_pair_kernel)
                     for (const Op* o : sel) {
-                        if (ty == OP_CHAIN && o->chain.variant == 4) {
-                            if (pending && pending->chain.hw == o->chain.hw && pending->chain.ncol == o->chain.ncol && pending->chain.M == o->chain.M) {
-                                Launch& Lp = pr.launches[launch_of[pending - pr.ops.data()]];
-                                Lp.chain2 = o->chain; Lp.chain_pair = true;
-                                launch_of[o - pr.ops.data()] = launch_of[pending - pr.ops.data()];
-                                pending = nullptr;
-                                continue;
-                            }
-                            pending = o;
-                        }
                         Launch L;
                         L.type = (OpType)ty;
                         L.op = *o;
@@ -1709,7 +1652,7 @@ struct fql_engine {
                     std::vector<GemmTask> tb;
                     for (const Op* o : sel) {
                         GemmTask t = o->gemm;
-                        static const int tmt_side = getenv("FQL_TMT") ? atoi(getenv("FQL_TMT")) : 1;
+                        constexpr int tmt_side = 1;
                         t.wk = (t.N <= 16) ? 4 : 2;
                         // throughput lane: two 16-row tiles per workgroup share each B fragment
                         t.tmt = (lane == 1 && tmt_side == 2 && t.M % 32 == 0 && t.M >= 256 && t.N >= 32) ? 2 : 1;
@@ -1728,7 +1671,7 @@ struct fql_engine {
                     std::vector<GemmTask> tb;
                     for (const Op* o : sel) {
                         GemmTask t = o->gemm;
-                        static const int ri_env = getenv("FQL_G64_RI") ? atoi(getenv("FQL_G64_RI")) : 0;
+                        constexpr int ri_env = 0;
                         const int ri = ri_env ? ri_env : (t.M >= 1024 && t.M % 64 == 0 ? 2 : 1);
                         t.wk = 2; t.tmt = ri;  // row tiles per wave: workgroup tile (32 ri) x 64
                         t.ntn = t.N / 64;
@@ -1801,7 +1744,6 @@ struct fql_engine {
             else if (o.type == OP_CHAIN) {
                 const double H = cfg.actor_hidden[0];
                 m = (double)o.chain.M * H * H + (o.chain.variant == 0 ? (double)o.chain.M * 16.0 * H : 0.0) + (o.chain.variant == 2 ? (double)o.chain.M * H * o.chain.ap : 0.0);
-                if (o.chain.variant == 4) m = (double)o.chain.M * o.chain.hw * o.chain.ncol;
             }
             else if (o.type == OP_XCHAIN) {
                 const Net& nb = nets[NET_BC];
@@ -1860,8 +1802,8 @@ struct fql_engine {
         else hipLaunchKernelGGL(k, g, b, l, st, __VA_ARGS__);                                     \
     } while (0)
     void issue(const Launch& L, hipStream_t s, int tl) {
-        static const bool u8_split = getenv("FQL_U8_SPLIT") == nullptr || atoi(getenv("FQL_U8_SPLIT")) != 0;
-        static const int side_prio = getenv("FQL_SIDE_PRIO") ? atoi(getenv("FQL_SIDE_PRIO")) : 0;
+        constexpr bool u8_split = true;
+        constexpr int side_prio = 0;
         switch (L.type) {
             case OP_GEMM:
                 if (L.euler && L.kbig) FQL_LAUNCH((fql_gemm16_euler_kernel<true>), dim3(L.grid), dim3(FQL_THREADS), L.lds, s, (const GemmTask*)L.table, L.ntasks, tl);
@@ -1967,11 +1909,11 @@ struct fql_engine {
             case OP_CHAIN: {
                 ChainArgs ca = L.op.chain; ca.tl = tl;
                 {   // XCD-aware tile order of the chain launches (16-row tiles x 32-column tiles)
-                    static const bool xcd_order = getenv("FQL_NO_XCD") == nullptr;
-                    const int ntm = ca.M / 16, ntn = (ca.variant == 4 ? ca.ncol : cfg.actor_hidden[0]) / 32;
+                    constexpr bool xcd_order = true;
+                    const int ntm = ca.M / 16, ntn = cfg.actor_hidden[0] / 32;
                     ca.xg = 0;
-                    if (xcd_order && ca.variant != 4) {
-                        static const int gm_env = getenv("FQL_XCD_GM_CHAIN") ? atoi(getenv("FQL_XCD_GM_CHAIN")) : 0;
+                    if (xcd_order) {
+                        constexpr int gm_env = 0;
                         double best = 1e30;
                         for (int gm : {1, 2, 4, 8}) {
                             const int gn = 8 / gm;
@@ -1980,18 +1922,6 @@ struct fql_engine {
                             if (cost < best) { best = cost; ca.xg = gm; }
                         }
                     }
-                }
-                if (ca.variant == 4) {   // fused LayerNorm-backward + dgrad level of the critic's Q-gradient chain (fp32 operands in both precisions)
-                    const dim3 g4((ca.M / 16) * (ca.ncol / 32), L.chain_pair ? 2 : 1);
-                    if (L.chain_pair) {
-                        ChainPair cp; cp.t[0] = ca; cp.t[1] = L.chain2; cp.t[1].tl = tl;
-                        if (ca.hw == 512) FQL_LAUNCH((fql_chain_pair_kernel<512, 4>), g4, dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, cp);
-                        else FQL_LAUNCH((fql_chain_pair_kernel<256, 4>), g4, dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(256), s, cp);
-                    } else {
-                        if (ca.hw == 512) FQL_LAUNCH((fql_chain_kernel<512, 4>), g4, dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(512), s, ca);
-                        else FQL_LAUNCH((fql_chain_kernel<256, 4>), g4, dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(256), s, ca);
-                    }
-                    break;
                 }
                 if (cfg.precision == 2 && ca.variant != 3) {   // (variant D keeps fp32 operands: its dZ / W arrive as fp32 and splitting both in the kernel costs what the MFMAs save)
 #define FQL_CHAIN_SPLIT(HH, VV) FQL_LAUNCH((fql_chain_split_kernel<HH, VV>), dim3((L.op.chain.M / 16) * (HH / 32)), dim3(FQL_CHAIN_THREADS), FQL_CHAIN_LDS_BYTES(HH), s, ca)
@@ -2141,57 +2071,19 @@ struct fql_engine {
         if (!err0.empty()) throw HipError{err0};
     }
 
-    // s2 != nullptr: two-stream issue (graph capture of a two-lane program); otherwise everything goes to `s0` in
-    // emission order, which is a topological order of the program.
+    // fork = true: the lanes of a multi-lane program on the lane streams (graph capture, or eager issue with FQL_NO_GRAPH=2); otherwise
+    // everything goes to `s0` in emission order, which is a topological order of the program.
     void run_launches(Program& pr, hipStream_t s0, bool fork = false) {
         const bool par = fork && pr.two_lanes;
         hipStream_t ls[FQL_LANES] = {s0, stream2, stream3, stream4};
-        // FQL_FORK_ALL=1 (experiment): lane 0 on a forked stream too, so the origin stream carries nothing but the fork / join events
-        static const bool fork_all = getenv("FQL_FORK_ALL") != nullptr;
         if (par) {
             if (!pr.ev_fork) HIP_CHECK(hipEventCreateWithFlags(&pr.ev_fork, hipEventDisableTiming));
             HIP_CHECK(hipEventRecord(pr.ev_fork, s0));
-            if (fork_all) { ls[0] = stream3; HIP_CHECK(hipStreamWaitEvent(stream3, pr.ev_fork, 0)); }
             for (int l = 1; l < FQL_LANES; ++l) if (pr.lane_used[l]) HIP_CHECK(hipStreamWaitEvent(ls[l], pr.ev_fork, 0));
         }
-        static const int only_lane = getenv("FQL_ONLY_LANE") ? atoi(getenv("FQL_ONLY_LANE")) : -1;  // timing experiments
-        static const int blocker_us = getenv("FQL_BLOCKER") ? atoi(getenv("FQL_BLOCKER")) : 0;
-        if (blocker_us > 0 && par && pr.launches.size() > 20) {   // experiment: take `FQL_BLOCKER_N` CUs away for blocker_us
-            static const int nb = getenv("FQL_BLOCKER_N") ? atoi(getenv("FQL_BLOCKER_N")) : 128;
-            static bool attr = false;
-            const size_t lds = 115 * 1024;
-            if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)fql_blocker_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-            HIP_CHECK(hipStreamWaitEvent(ls[3], pr.ev_fork, 0));
-            hipLaunchKernelGGL(fql_blocker_kernel, dim3(nb), dim3(FQL_THREADS), lds, ls[3], (unsigned long long)blocker_us * 100ull);
-            pr.lane_used[3] = true;
-        }
-        // FQL_CAPTURE_GROUPED=1 (experiment): issue - and so capture - the launches stretch by stretch (a lane's launches between two cross-lane
-        // dependencies back to back; stretches in the order of their first launch, which is still a topological order) instead of level by level
-        static const bool grouped = getenv("FQL_CAPTURE_GROUPED") != nullptr && atoi(getenv("FQL_CAPTURE_GROUPED")) != 0;
-        std::vector<int> order;
-        if (grouped && par) {
-            std::vector<std::vector<int>> st;
-            int cur[FQL_LANES];
-            for (int l = 0; l < FQL_LANES; ++l) cur[l] = -1;
-            for (int li = 0; li < (int)pr.launches.size(); ++li) {
-                const Launch& L = pr.launches[li];
-                if (cur[L.lane] < 0 || !L.waits.empty()) { st.emplace_back(); cur[L.lane] = (int)st.size() - 1; }
-                st[cur[L.lane]].push_back(li);
-                if (L.record_after) cur[L.lane] = -1;
-            }
-            for (const auto& v : st) for (int li : v) order.push_back(li);
-        } else {
-            for (int li = 0; li < (int)pr.launches.size(); ++li) order.push_back(li);
-        }
-        for (int oi : order) {
-            Launch& L = pr.launches[oi];
-            static const int max_launch = getenv("FQL_MAX_LAUNCH") ? atoi(getenv("FQL_MAX_LAUNCH")) : -1;   // capture-crash bisection
-            if (max_launch >= 0 && (int)(&L - pr.launches.data()) >= max_launch) continue;
-            if (only_lane >= 0 && pr.two_lanes && L.lane != only_lane) continue;
-            static const int skip_lane = getenv("FQL_SKIP_LANE") ? atoi(getenv("FQL_SKIP_LANE")) : -1;
-            if (skip_lane >= 0 && pr.two_lanes && L.lane == skip_lane && L.type != OP_PREP) continue;
+        static const bool trace_l = getenv("FQL_TRACE") != nullptr;
+        for (Launch& L : pr.launches) {
             hipStream_t s = par ? ls[L.lane] : s0;
-            static const bool trace_l = getenv("FQL_TRACE") != nullptr;
             if (trace_l) {
                 fprintf(stderr, "[fql] launch %d type %d lane %d grid %d waits %zu:", (int)(&L - pr.launches.data()), (int)L.type, L.lane, L.grid, L.waits.size());
                 for (int w : L.waits) fprintf(stderr, " %d(lane %d)", w, pr.launches[w].lane);
@@ -2204,12 +2096,6 @@ struct fql_engine {
                 if (!L.ev) HIP_CHECK(hipEventCreateWithFlags(&L.ev, hipEventDisableTiming));
                 HIP_CHECK(hipEventRecord(L.ev, s));
             }
-        }
-        if (par && fork_all) {
-            static hipEvent_t ev0 = nullptr;
-            if (!ev0) HIP_CHECK(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
-            HIP_CHECK(hipEventRecord(ev0, stream3));
-            HIP_CHECK(hipStreamWaitEvent(s0, ev0, 0));
         }
         if (par)
             for (int l = 1; l < FQL_LANES; ++l) {
@@ -2242,75 +2128,8 @@ struct fql_engine {
             hipGraphGetNodes(pr.graph, nullptr, &nn);
             fprintf(stderr, "[fql] instantiate (%zu nodes)\n", nn);
         }
-        if (const char* dot = getenv("FQL_DOT")) {   // diagnostics: dump every captured graph (nodes + edges) as graphviz
-            static int ndot = 0;
-            char path[512];
-            snprintf(path, sizeof path, "%s.%d.dot", dot, ndot++);
-            (void)hipGraphDebugDotPrint(pr.graph, path, 0);
-        }
         HIP_CHECK(hipGraphInstantiate(&pr.exec, pr.graph, nullptr, nullptr, 0));
         if (trace_c) fprintf(stderr, "[fql] instantiated\n");
-    }
-
-    // FQL_SEG_GRAPHS=1: the update as a handful of LINEAR graphs, one per stretch of a lane between two cross-lane dependencies, launched on the lane
-    // streams with real events between them.  hipGraphLaunch of the whole three-lane graph costs the host ~300 us (3.6 us per node: a multi-queue graph is
-    // walked node by node) - as much as the update takes on the device; a linear graph of the same nodes costs ~0.5 us per node (measured with
-    // DEBUG_HIP_FORCE_GRAPH_QUEUES=1: 37 us for all 83).
-    void build_segments(Program& pr) {
-        int cur[FQL_LANES];
-        for (int l = 0; l < FQL_LANES; ++l) cur[l] = -1;
-        for (int li = 0; li < (int)pr.launches.size(); ++li) {
-            const Launch& L = pr.launches[li];
-            if (cur[L.lane] < 0 || !L.waits.empty()) {
-                pr.segs.emplace_back();
-                pr.segs.back().lane = L.lane;
-                cur[L.lane] = (int)pr.segs.size() - 1;
-            }
-            pr.segs[cur[L.lane]].idx.push_back(li);
-            if (L.record_after) cur[L.lane] = -1;
-        }
-        // (segments were opened in launch order = a topological order: a segment's only waits are those of its first launch)
-        HIP_CHECK(hipStreamSynchronize(stream));
-        for (Program::Seg& sg : pr.segs) {
-            HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-            try {
-                for (int li : sg.idx) issue(pr.launches[li], stream, (&pr == &prog_full) ? li : -1);
-            } catch (...) {
-                hipGraph_t g = nullptr;
-                hipStreamEndCapture(stream, &g);
-                if (g) hipGraphDestroy(g);
-                throw;
-            }
-            HIP_CHECK(hipStreamEndCapture(stream, &sg.graph));
-            HIP_CHECK(hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0));
-        }
-        if (getenv("FQL_TRACE")) fprintf(stderr, "[fql] %zu segment graphs for %zu launches\n", pr.segs.size(), pr.launches.size());
-    }
-    void run_segments(Program& pr, hipStream_t s0) {
-        if (pr.segs.empty()) build_segments(pr);
-        hipStream_t ls[FQL_LANES] = {s0, stream2, stream3, stream4};
-        if (pr.two_lanes) {
-            if (!pr.ev_fork) HIP_CHECK(hipEventCreateWithFlags(&pr.ev_fork, hipEventDisableTiming));
-            HIP_CHECK(hipEventRecord(pr.ev_fork, s0));
-            for (int l = 1; l < FQL_LANES; ++l) if (pr.lane_used[l]) HIP_CHECK(hipStreamWaitEvent(ls[l], pr.ev_fork, 0));
-        }
-        for (Program::Seg& sg : pr.segs) {
-            hipStream_t s = ls[sg.lane];
-            for (int w : pr.launches[sg.idx.front()].waits) if (pr.launches[w].ev) HIP_CHECK(hipStreamWaitEvent(s, pr.launches[w].ev, 0));
-            HIP_CHECK(hipGraphLaunch(sg.exec, s));
-            Launch& last = pr.launches[sg.idx.back()];
-            if (last.record_after) {
-                if (!last.ev) HIP_CHECK(hipEventCreateWithFlags(&last.ev, hipEventDisableTiming));
-                HIP_CHECK(hipEventRecord(last.ev, s));
-            }
-        }
-        if (pr.two_lanes)
-            for (int l = 1; l < FQL_LANES; ++l) {
-                if (!pr.lane_used[l]) continue;
-                if (!pr.ev_join[l]) HIP_CHECK(hipEventCreateWithFlags(&pr.ev_join[l], hipEventDisableTiming));
-                HIP_CHECK(hipEventRecord(pr.ev_join[l], ls[l]));
-                HIP_CHECK(hipStreamWaitEvent(s0, pr.ev_join[l], 0));
-            }
     }
 
     // one graph per segment: seg 0 = lane-0 launches up to the last one lane 1 waits on, seg 1 = lane 1, seg 2 = lane 0 up to
@@ -2380,7 +2199,6 @@ struct fql_engine {
     void free_program(Program& pr) {
         if (pr.exec) hipGraphExecDestroy(pr.exec);
         if (pr.graph) hipGraphDestroy(pr.graph);
-        for (Program::Seg& sg : pr.segs) { if (sg.exec) hipGraphExecDestroy(sg.exec); if (sg.graph) hipGraphDestroy(sg.graph); }
         for (Launch& L : pr.launches) if (L.ev) hipEventDestroy(L.ev);
         if (pr.ev_fork) hipEventDestroy(pr.ev_fork);
         for (hipEvent_t e : pr.ev_join) if (e) hipEventDestroy(e);
@@ -2417,7 +2235,7 @@ struct fql_engine {
             // One batch-assembly launch per lane (state agents): the side lane then has no dependency on the critical lane at the
             // start of the update.  (On this runtime a graph branch whose first node waits for a node of the other branch starts
             // only ~16 launches of that branch later: profiles/r02_timeline_concurrent.txt.)
-            static const bool split_prep = getenv("FQL_NO_SPLIT_PREP") == nullptr;
+            constexpr bool split_prep = true;
             if (visual) {
                 op.prep.E_c = eb_c.E; op.prep.E_t = eb_t.E; op.prep.E_bc = eb_bc.E; op.prep.E_os = eb_os.E;
                 op.reads = {eb_c.E, eb_t.E, eb_bc.E, eb_os.E};
@@ -2443,7 +2261,7 @@ struct fql_engine {
         // the critic-loss passes, the BC pass, every weight gradient and Adam go to lane 2.  Edges between the two forked
         // lanes run 1 -> 2 only: torch's bundled HIP runtime recurses forever in hipStreamEndCapture when two forked streams wait
         // on each other in BOTH directions (hip::Stream::EndCapture walks the cycle; the system ROCm 7.2 runtime does not).
-        static const bool lanes3_env = getenv("FQL_LANES3") ? atoi(getenv("FQL_LANES3")) != 0 : true;
+        constexpr bool lanes3_env = true;
         const bool lanes3 = lanes3_env && !visual && !split_build;
         const int fill_lane = lanes3 ? 2 : 1;
         if (!split_build) fill_lane_full = fill_lane;
@@ -2464,7 +2282,7 @@ struct fql_engine {
         for (int e = 0; e < 2; ++e) emit_forward(pr, p_c1[e], with_grads);
         // three lanes: the target-critic pass rides on lane 1 (its action block comes from the one-step forward there, and lane 1 is otherwise
         // idle once the Q-gradient path has ended): 2500 -> 2580 updates/s in steady state
-        static const int ct_lane3 = getenv("FQL_CT_LANE3") ? atoi(getenv("FQL_CT_LANE3")) : -1;   // (three-lane programs only: the others have no lane 2)
+        constexpr int ct_lane3 = -1;   // (three-lane programs only: the others have no lane 2)
         place("ct", lanes3 ? (ct_lane3 >= 0 ? ct_lane3 : 1) : fill_lane, true);
         for (int e = 0; e < 2; ++e) emit_forward(pr, p_ct[e], false);
         place("c1", fill_lane, true);
@@ -2482,21 +2300,21 @@ struct fql_engine {
         // The critic's weight gradients gate nothing but Adam: they are emitted after the Q-gradient chain, whose levels on lane 1
         // then carry fewer tiles and finish earlier - and with them the one-step actor's backward tail (2127 -> 2170 updates/s;
         // deferring the BC flow's too: 2161, the critic's whole backward chain: 2050).  FQL_LATE_WGRAD: 0 off, 1 both, 2 critic, 3 bc.
-        static const int late_wgrad_env = getenv("FQL_LATE_WGRAD") ? atoi(getenv("FQL_LATE_WGRAD")) : -1;
+        constexpr int late_wgrad_env = -1;
         const int late_wgrad = late_wgrad_env >= 0 ? late_wgrad_env : (lanes3 ? 0 : 2);   // (three lanes: they are on lane 2, out of the Q-gradient path's launches anyway)
         std::vector<Op> late_ops;
         if ((late_wgrad == 1 || late_wgrad == 2) && with_grads) defer_wgrads = &late_ops;
         if (with_grads)
             for (int e = 0; e < 2; ++e) emit_backward(pr, p_c1[e], 0, B, true, visual);
         // (not in the data-parallel split program: there lane 1 must finish bucket 0 without waiting for lane 0's tail)
-        const bool enc_align = getenv("FQL_NO_ENC_ALIGN") == nullptr && !split_build;
+        const bool enc_align = !split_build;
         if (with_grads && visual && !enc_align) {   // the critic's encoder sees the critic loss only (the actor loss uses stored params)
             place("enc", 1, true);
             emit_encoder_backward(pr, eb_c, 0, B, p_c1[0].dx0, p_c1[1].dx0, nets[NET_C0].in_p());
         }
         // BC flow-matching pass (fql.py:52-59).  FQL_BC_LATE=<lane> (three-lane programs): emitted BEHIND the Q-gradient path on that lane instead of
         // on lane 2 in front of it - lane 1 idles from the end of the Q-gradient path to the end of the update while lane 2 carries the longest tail.
-        static const int bc_late_env = getenv("FQL_BC_LATE") ? atoi(getenv("FQL_BC_LATE")) : 0;
+        constexpr int bc_late_env = 0;
         const int bc_late = (lanes3 && with_grads) ? bc_late_env : 0;
         auto emit_bc = [&](int bc_lane) {
             place("bcf", bc_lane, true);
@@ -2538,7 +2356,7 @@ struct fql_engine {
         defer_wgrads = nullptr;
         if (with_grads) {
             // two lanes: in phase with the c1 chain (shared launches); three lanes: on its own, as early as its inputs exist
-            static const bool c2_align = getenv("FQL_NO_C2_ALIGN") == nullptr;
+            constexpr bool c2_align = true;
             for (int e = 0; e < 2; ++e) emit_backward(pr, p_c2[e], 0, B, false, true, (c2_align && !lanes3) ? I_CR : nullptr);
         }
         for (Op& w : late_ops) {   // the critic's and the BC flow's weight gradients only after the Q-gradient chain (they gate nothing)
@@ -2553,8 +2371,8 @@ struct fql_engine {
         // FQL_FUSE_EF=1: the last Euler step's target is finished inside the one-step head dgrad's prologue (GF_A_EULFIN: one launch less on the
         // critical lane).  Built, parity-green (bit-identical target) and measured no faster - bf16x3 3037 -> 3018, fp32 2555 -> 2550 updates/s: the 16
         // partial loads per element lengthen the prologue of all 256 workgroups by what the launch boundary saved - so it is opt-in.
-        static const bool fuse_ef_env = getenv("FQL_FUSE_EF") != nullptr && atoi(getenv("FQL_FUSE_EF")) != 0;
-        euler_finish_fused = fuse_ef_env && with_grads && getenv("FQL_NO_FUSE_LA") == nullptr && !cfg.actor_layer_norm && !use_pec && !use_xchain && fused_euler && use_chain &&
+        constexpr bool fuse_ef_env = false;
+        euler_finish_fused = fuse_ef_env && with_grads && !cfg.actor_layer_norm && !use_pec && !use_xchain && fused_euler && use_chain &&
                              fs > 1 && vp_tiles <= 32;
         if (use_xchain) emit_euler_xcd(pr);
         else if (use_pec) emit_euler_persistent(pr);
@@ -2566,7 +2384,7 @@ struct fql_engine {
                          (float)(s + 1) / (float)fs);
         // The actor-loss gradient is built inside the one-step actor's head dgrad (GF_A_LOSSACT), so the loss kernel only
         // reports scalars and leaves the critical path (it rides on lane 1): 2083 -> 2130 updates/s.
-        static const bool fuse_la_env = getenv("FQL_NO_FUSE_LA") == nullptr;
+        constexpr bool fuse_la_env = true;
         const bool fuse_la = with_grads && fuse_la_env && !cfg.actor_layer_norm;
         Op la_op{};
         int la_lane = 0;
@@ -2585,7 +2403,7 @@ struct fql_engine {
             }
             // FQL_TAIL_MERGE (see adam_for; default on): this kernel, first of lane 2's tail, also takes the edge to the end of lane 1's Q-gradient chain that
             // the critic's Adam behind it needs (write after read of the critic's kernels) - both cross-lane waits of the tail on ONE launch
-            static const bool tail_merge = getenv("FQL_TAIL_MERGE") == nullptr || atoi(getenv("FQL_TAIL_MERGE")) != 0;   // default on
+            constexpr bool tail_merge = true;   // default on
             if (tail_merge && with_grads && !kgrad) { op.reads.push_back(p_c2[0].dx0); op.reads.push_back(p_c2[1].dx0); }
             const int keep = emit_lane;
             if (fuse_la && !split_build) emit_lane = fill_lane;
@@ -2597,7 +2415,7 @@ struct fql_engine {
             // The one-step actor's weight gradients gate the last Adam launch.  On lane 1 they would queue behind the deferred critic
             // weight gradients and the other two Adam launches; emitted here as ONE launch on lane 0 behind the last dgrad they
             // cost ~10 us of tail instead.  (FQL_OS_WGRAD_SIDE=1: the old placement.)
-            static const bool os_w_side = getenv("FQL_OS_WGRAD_SIDE") != nullptr;
+            constexpr bool os_w_side = false;
             std::vector<Op> os_w;
             if (!os_w_side) defer_wgrads = &os_w;
             const size_t first = pr.ops.size();
@@ -2641,7 +2459,7 @@ struct fql_engine {
             }
             // Three lanes: lane 2 is idle by the time the tail runs, so each layer's weight gradient goes there as soon as its dz exists
             // (beside the remaining dgrads of the tail); only the first layer's small one is left behind the last dgrad.
-            static const int os_w_l2_env = getenv("FQL_OS_WGRAD_LANE2") ? atoi(getenv("FQL_OS_WGRAD_LANE2")) : -1;
+            constexpr int os_w_l2_env = -1;
             const bool os_w_l2 = lanes3 && (os_w_l2_env >= 0 ? os_w_l2_env != 0 : false);
             for (Op& w : os_w) {
                 if (!os_w_l2) w.reads.push_back(p_os_bwd.dz[0]);   // after the last dgrad: all five in one launch
@@ -2680,7 +2498,7 @@ struct fql_engine {
             if (m2 >= 0) { a.adam_c1 = mod_chunk0[m2]; a.adam_n1 = mod_chunkn[m2]; a.writes.push_back(d_partials + mod_chunk0[m2] * 4); }
             // FQL_TAIL_MERGE (default on; =0 off): the critic's Adam, the first launch of lane 2's tail, also waits for the Euler target the actor-loss kernel behind it reads -
             // one launch with two cross-lane edges instead of two launches with one each (every such edge costs the waiting lane ~10 us)
-            static const bool tail_merge = getenv("FQL_TAIL_MERGE") == nullptr || atoi(getenv("FQL_TAIL_MERGE")) != 0;   // default on
+            constexpr bool tail_merge = true;   // default on
             if (tail_merge && m == 2 && tgt) a.reads.push_back(tgt);
             for (int mm : {m, m2}) if (visual && mm >= 0) {
                 const int m = mm;
@@ -2759,7 +2577,7 @@ struct fql_engine {
         DevState* st = d_state;
         // the critic's and the BC flow's Adam as ONE launch (FQL_ADAM_MERGE=0: two): both sit at the end of the same lane behind the same
         // dependencies, and every graph node costs the host 3-4 us
-        static const bool adam_merge = getenv("FQL_ADAM_MERGE") == nullptr || atoi(getenv("FQL_ADAM_MERGE")) != 0;
+        constexpr bool adam_merge = true;
         if (adam_merge) adam_for(pr, 2, {NET_C0, NET_C1, NET_BC}, fill_lane_full, 0);
         else {
             adam_for(pr, 2, {NET_C0, NET_C1}, fill_lane_full);
@@ -2836,7 +2654,7 @@ struct fql_engine {
         {   // fused Euler chain (layers 0+1 and last-hidden+head per launch): plain actor MLPs with >= 2 hidden layers
             const Net& nb = nets[NET_BC];
             const int nh = nb.nl() - 1;
-            fused_euler = getenv("FQL_NO_FUSED_EULER") == nullptr && !cfg.actor_layer_norm && ad <= 15 && nh >= 3;   // 16-wide rank update: act + t
+            fused_euler = !cfg.actor_layer_norm && ad <= 15 && nh >= 3;   // 16-wide rank update: act + t
             if (fused_euler) {
                 X_e0 = dalloc(W, (size_t)B * inp_b);
                 C0 = dalloc(W, (size_t)B * nb.layers[0].out_p);
@@ -2940,14 +2758,14 @@ struct fql_engine {
         FQL_TR("scheduled");
         capture(prog_fwdbwd); FQL_TR("captured fwdbwd"); capture(prog_opt); capture(prog_loss);
         FQL_TR("captured");
-        if (getenv("FQL_NO_FULL") == nullptr) {
+        {
             build_full_program(prog_full);
             schedule(prog_full, W);
             FQL_TR("scheduled full");
             capture(prog_full);
             FQL_TR("captured full");
         }
-        if (getenv("FQL_NO_SPLIT") == nullptr) {
+        {
             split_build = true;
             build_step_program(prog_split, true);
             split_build = false;
@@ -3334,26 +3152,11 @@ int fql_create(const fql_config* cfg, uint64_t seed, fql_handle* out) {
         }
         // (stream priorities were tried for the graph lanes in round 1: no gain with two streams, a 4x slowdown with three)
         h->num_cus = prop.multiProcessorCount;
-        if (const char* cm = getenv("FQL_CUMASK")) {  // experiment: disjoint CU sets for the two lanes (host-launched lane graphs)
-            const uint32_t m0 = (uint32_t)strtoul(cm, nullptr, 16);
-            std::vector<uint32_t> a(8, m0), b(8, ~m0);
-            HIP_CHECK(hipExtStreamCreateWithCUMask(&h->stream, 8, a.data()));
-            HIP_CHECK(hipExtStreamCreateWithCUMask(&h->stream2, 8, b.data()));
-            HIP_CHECK(hipExtStreamCreateWithCUMask(&h->stream3, 8, b.data()));
-            HIP_CHECK(hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking));
-        } else {
-            // FQL_LANE_PRIO=1 (experiment): the engine's own stream at the highest queue priority, the extra lanes at the lowest, so the
-            // latency-bound Euler chain on lane 0 gets free CU slots before the throughput work of the other lanes
-            int lo = 0, hi = 0;
-            HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            const int mode = getenv("FQL_LANE_PRIO") ? atoi(getenv("FQL_LANE_PRIO")) : 0;
-            const int p0 = (mode & 1) ? hi : 0, px = (mode & 2) ? lo : 0;
-            if (getenv("FQL_TRACE")) fprintf(stderr, "[fql] stream priority range lo %d hi %d -> lane0 %d others %d\n", lo, hi, p0, px);
-            HIP_CHECK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, p0));
-            HIP_CHECK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, px));
-            HIP_CHECK(hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, px));
-            HIP_CHECK(hipStreamCreateWithPriority(&h->stream4, hipStreamNonBlocking, px));
-        }
+        // (stream priorities and CU masks were tried for the graph lanes in rounds 1-2: no gain with two streams, a 4x slowdown with three)
+        HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking));
         h->build_nets();
         HIP_CHECK(hipMalloc((void**)&h->P, h->n_total * sizeof(float)));
         HIP_CHECK(hipMalloc((void**)&h->G, h->n_train * sizeof(float)));
@@ -3496,16 +3299,12 @@ int fql_set_step(fql_handle h, int64_t adam_count, int64_t train_step) {
 static hipStream_t pick(fql_handle h, void* s) { return s ? (hipStream_t)s : h->stream; }
 
 static void run_program(fql_handle h, Program& pr, hipStream_t s) {
-    static const bool no_graph = getenv("FQL_NO_GRAPH") != nullptr;
-    static const bool eager_lanes = getenv("FQL_NO_GRAPH") && atoi(getenv("FQL_NO_GRAPH")) == 2;   // eager launches on the lane streams
-    static const bool split_default = getenv("FQL_SPLIT_DEFAULT") != nullptr;  // experiment: host-launched lane graphs
-    static const bool threaded = getenv("FQL_NO_GRAPH") && atoi(getenv("FQL_NO_GRAPH")) == 3;      // ... one host thread per lane
-    static const bool seg_graphs = getenv("FQL_SEG_GRAPHS") != nullptr && atoi(getenv("FQL_SEG_GRAPHS")) != 0;   // linear graphs per lane stretch, real events between
-    if (seg_graphs && !no_graph && pr.two_lanes) h->run_segments(pr, s);
-    else if (threaded) h->run_threaded(pr, s);
-    else if (eager_lanes) h->run_launches(pr, s, true);
+    // FQL_NO_GRAPH (diagnostics; the captured graph is the product path): 1 = eager launches on one stream, 2 = eager launches on the lane
+    // streams, 3 = one host thread per lane (run_threaded; tests/test_gpu_streams.py runs the parity suite under it)
+    static const int no_graph = getenv("FQL_NO_GRAPH") ? atoi(getenv("FQL_NO_GRAPH")) : 0;
+    if (no_graph == 3) h->run_threaded(pr, s);
+    else if (no_graph == 2) h->run_launches(pr, s, true);
     else if (no_graph) h->run_launches(pr, s);
-    else if (split_default && (&pr == &h->prog_fwdbwd) && h->split_ok && s != h->stream2) h->launch_split(s, h->stream2);
     else HIP_CHECK(hipGraphLaunch(pr.exec, s));
 }
 

@@ -2617,16 +2617,6 @@ __global__ __launch_bounds__(FQL_THREADS) void fql_enc_dz_kernel(const EncDzArgs
     stg(P.dz + e, g * ldg(P.z + e));   // P.z holds GELU'(z) (GF_SAVE_Z)
 }
 
-// Experiment only (FQL_BLOCKER): occupies one CU per workgroup (its dynamic LDS leaves no room for a side-lane
-// workgroup) for `ticks` of the 100 MHz wall clock, to measure what the other lane does on the remaining CUs.
-__global__ __launch_bounds__(FQL_THREADS) void fql_blocker_kernel(unsigned long long ticks) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    if (threadIdx.x == 0) lds[0] = 0.f;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-}
-
-// sample_actions / flow_actions input assembly: X[n_pad, inp] = concat(obs, noise[, t=0])
 struct AssembleArgs {
     const float *obs, *noise;  // noise null => RNG keyed by (key, seed)
     float* X;
