@@ -962,14 +962,13 @@ struct fql_engine {
         return true;
     }
 
-    // per-pass placement: lane and kernel family (env overrides FQL_LANE_<pass>, FQL_K16_<pass> for experiments)
+    // per-pass placement: lane and kernel family (FQL_LANE_<pass> overrides the lane: tests/test_gpu_streams.py provokes the refusal of a two-way edge with it)
     void place(const char* pass, int default_lane, bool default64) {
         char key[64];
         snprintf(key, sizeof key, "FQL_LANE_%s", pass);
         const char* e = getenv(key);
         emit_lane = e ? atoi(e) : default_lane;
-        snprintf(key, sizeof key, "FQL_K16_%s", pass);
-        allow64 = getenv(key) ? false : default64;
+        allow64 = default64;
     }
 
     void push(Program& pr, Op& op) {
@@ -2699,7 +2698,7 @@ struct fql_engine {
         use_xchain = xchain_eligible();
         if (use_xchain) {
             const Net& nb = nets[NET_BC];
-            x_wlds = getenv("FQL_XCHAIN_WLDS") == nullptr || atoi(getenv("FQL_XCHAIN_WLDS")) != 0;   // (=0: kernels streamed into registers, 16 KB of LDS: 319 us for the chain)
+            x_wlds = true;   // (false: kernels streamed into registers behind each arrival, 16 KB of LDS - measured 319 us for the chain against 136)
             x_lds = (size_t)FQL_XCHAIN_LDS_FLOATS(nb.nl() - 2, nb.layers[0].out_p, x_wlds) * sizeof(float);
             int per_cu = 0;   // every workgroup waits for its XCD's other 31: all 256 must be resident, one per CU
             const void* kf = x_wlds ? (const void*)fql_xchain_kernel<true> : (const void*)fql_xchain_kernel<false>;
