@@ -84,11 +84,11 @@ def visual_params(seed, hw, c, ad, cfg):
     return O.tree_map(lambda a: a.astype(np.float32), params)
 
 
-def visual_case():
-    """BASELINE configs[4] in miniature: uint8 [B,32,32,3] observations, impala_small encoders."""
-    name, hw, c, ad, B, hidden, seed = 'visual_small', 32, 3, 4, 16, (32, 32, 32, 32), 4242
+def visual_case(name='visual_small', hw=32, c=3, ad=4, B=16, hidden=(32, 32, 32, 32), seed=4242, alpha=3.0):
+    """BASELINE configs[4] in miniature: uint8 [B,32,32,3] observations, impala_small encoders; and (visual_full) at
+    its real image size and widths: [B,64,64,9], hidden 512 x 4, alpha 300, batch 64 (the smallest the engine's encoder Dense takes)."""
     cfg = O.get_config()
-    cfg.update(actor_hidden_dims=hidden, value_hidden_dims=hidden, batch_size=B, alpha=3.0, encoder='impala_small')
+    cfg.update(actor_hidden_dims=hidden, value_hidden_dims=hidden, batch_size=B, alpha=alpha, encoder='impala_small')
     params = visual_params(seed, hw, c, ad, cfg)
     rng = np.random.default_rng(seed + 2)
     batch = {'observations': rng.integers(0, 256, size=(B, hw, hw, c), dtype=np.uint8),
@@ -103,13 +103,16 @@ def visual_case():
     flow = ref.compute_flow_actions(batch['observations'], noise['z'])
     _, info_up = ref.update(batch, noise)
     paths = [p for p, _ in O.tree_leaves_with_path(grads)]
-    out = {'meta': json.dumps(dict(hw=hw, c=c, act_dim=ad, B=B, hidden=list(hidden), seed=seed, alpha=3.0, paths=paths))}
+    out = {'meta': json.dumps(dict(hw=hw, c=c, act_dim=ad, B=B, hidden=list(hidden), seed=seed, alpha=alpha, paths=paths))}
     for k, v in batch.items():
         out[f'batch/{k}'] = v
     for k, v in noise.items():
         out[f'noise/{k}'] = v
     out['grad_l2'] = np.array([np.sqrt(np.sum(np.square(g))) for _, g in O.tree_leaves_with_path(grads)])
     out['grad_sum'] = np.array([np.sum(g) for _, g in O.tree_leaves_with_path(grads)])
+    # a strided sample of every leaf's gradient (<= 64 elements each): element-level evidence without 20 MB of tensors
+    out['grad_sample'] = np.concatenate([g.reshape(-1)[::max(1, g.size // 64)][:64].astype(np.float64) for _, g in O.tree_leaves_with_path(grads)])
+    out['grad_max'] = np.array([np.abs(g).max() for _, g in O.tree_leaves_with_path(grads)])
     out['new_param_sum'] = np.array([np.sum(v.astype(np.float64)) for _, v in O.tree_leaves_with_path(ref.params)])
     out['total_loss'] = np.float64(loss)
     out['info_total_loss'] = np.array([float(info_tl[k]) for k in O.INFO_KEYS[:10]])
@@ -121,6 +124,10 @@ def visual_case():
 
 
 if __name__ == '__main__':
+    if '--visual-full-only' in sys.argv:
+        visual_case('visual_full', hw=64, c=9, ad=5, B=64, hidden=(512, 512, 512, 512), seed=4343, alpha=300.0)
+        sys.exit(0)
     if '--visual-only' not in sys.argv:
         main()
     visual_case()
+    visual_case('visual_full', hw=64, c=9, ad=5, B=64, hidden=(512, 512, 512, 512), seed=4343, alpha=300.0)

@@ -10,6 +10,7 @@ from oracle import fql_oracle as O
 
 GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), 'golden', '*.npz')) if 'visual' not in os.path.basename(p) and not os.path.basename(p).startswith('traj_'))
 VISUAL_GOLDEN = os.path.join(os.path.dirname(__file__), 'golden', 'visual_small.npz')
+VISUAL_FULL = os.path.join(os.path.dirname(__file__), 'golden', 'visual_full.npz')      # 64x64x9, hidden 512 x 4, alpha 300, B 64
 
 
 def load_case(path):
@@ -61,13 +62,18 @@ def test_oracle_reproduces_golden(path, dtype, rtol):
         assert abs(iu[k] - c['info_update'][i]) <= rtol * max(1, abs(c['info_update'][i])), k
 
 
-def load_visual_case():
-    """tests/golden/visual_small.npz: inputs + expected outputs; the parameters are regenerated from the stored seed."""
+def grad_sample(leaves):
+    """The fixture's strided sample of every gradient leaf (make_golden.visual_case): <= 64 elements per leaf, concatenated."""
+    return np.concatenate([np.asarray(g).reshape(-1)[::max(1, g.size // 64)][:64].astype(np.float64) for g in leaves])
+
+
+def load_visual_case(path=VISUAL_GOLDEN):
+    """tests/golden/visual_*.npz: inputs + expected outputs; the parameters are regenerated from the stored seed."""
     import importlib.util
     spec = importlib.util.spec_from_file_location('make_golden', os.path.join(os.path.dirname(__file__), 'golden', 'make_golden.py'))
     mg = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mg)
-    z = np.load(VISUAL_GOLDEN, allow_pickle=False)
+    z = np.load(path, allow_pickle=False)
     m = json.loads(str(z['meta']))
     cfg = O.get_config()
     cfg.update(actor_hidden_dims=tuple(m['hidden']), value_hidden_dims=tuple(m['hidden']), batch_size=m['B'], alpha=m['alpha'],
@@ -95,3 +101,22 @@ def test_oracle_reproduces_visual_golden(dtype, rtol):
     _, iu = ref.update(c['batch'], c['noise'])
     for i, k in enumerate(O.INFO_KEYS):
         assert abs(iu[k] - z['info_update'][i]) <= 10 * rtol * abs(z['info_update'][i]) + 1e-6, k
+
+
+def test_oracle_reproduces_full_size_visual_golden():
+    """tests/golden/visual_full.npz (BASELINE configs[4]'s shapes: uint8 [64,64,64,9], impala_small, hidden 512 x 4, alpha 300): the
+    fp32 oracle against the committed fp64 values -- loss terms, per-leaf gradient norms and the strided element sample."""
+    c = load_visual_case(VISUAL_FULL)
+    m, z = c['meta'], c['z']
+    assert (m['hw'], m['c'], m['B'], m['hidden']) == (64, 9, 64, [512] * 4)
+    ref = O.OracleFQL(c['params'], c['cfg'], (m['hw'], m['hw'], m['c']), m['act_dim'], np.float32)
+    _, info, g = ref.grads(c['batch'], c['noise'])
+    for i, k in enumerate(O.INFO_KEYS[:10]):
+        assert abs(info[k] - z['info_total_loss'][i]) <= 5e-4 * max(1.0, abs(z['info_total_loss'][i])), k
+    leaves = O.tree_leaves_with_path(g)
+    assert [p for p, _ in leaves] == m['paths']
+    l2 = np.array([np.sqrt(np.sum(np.square(v.astype(np.float64)))) for _, v in leaves])
+    np.testing.assert_allclose(l2, z['grad_l2'], rtol=1e-2, atol=1e-9)
+    gs = grad_sample([v for _, v in leaves])
+    scale = np.repeat(z['grad_max'], [min(64, len(v.reshape(-1)[::max(1, v.size // 64)])) for _, v in leaves])
+    assert np.mean(np.abs(gs - z['grad_sample']) <= 2e-3 * scale + 1e-12) >= 0.99
