@@ -89,5 +89,5 @@ def test_engine_reproduces_full_size_visual_golden(precision):
     scale = np.repeat(z['grad_max'], [len(g.reshape(-1)[::max(1, g.size // 64)][:64]) for g in grads])
     ok = np.abs(gs - z['grad_sample']) <= (1e-4 if precision == 'fp32' else 1e-3) * scale + 1e-12
     assert ok.mean() >= 0.98, (ok.mean(), np.abs(gs - z['grad_sample']).max())
-    dense = np.repeat([('encoder' not in p) for p in m['paths']], [len(g.reshape(-1)[::max(1, g.size // 64)][:64]) for g in grads])
+    dense = np.repeat([('stack_blocks' not in p) for p in m['paths']], [len(g.reshape(-1)[::max(1, g.size // 64)][:64]) for g in grads])
     assert ok[dense].all()                                                       # no pool upstream of the MLP leaves: every sampled element
