@@ -1,5 +1,8 @@
-import os, numpy as np
+import os, sys
 os.environ['FQL_DUMP']='1'
-import fql_amd
-cfg = fql_amd.get_config(); cfg['alpha']=10.0
-a = fql_amd.FQLAgent.create(0, np.zeros((1,29),np.float32), np.zeros((1,8),np.float32), cfg)
+sys.path.insert(0, os.getcwd())
+import numpy as np, fql_amd
+from tests.util import make_problem
+cfg, ds, batch, noise = make_problem(29, 8, 256, (512,)*4, seed=3)
+a = fql_amd.FQLAgent.create(0, batch['observations'][:1], batch['actions'][:1], cfg)
+a.update(batch, noise=noise)

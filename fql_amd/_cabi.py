@@ -84,6 +84,7 @@ SYMBOLS = {
     'fql_dataset_upload_frames': (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _I, _F]),
     'fql_update_from_frames': (_I, [_VP, _VP, _VP, _I, _I64, _I64, C.POINTER(FqlNoise), _VP, _VP]),
     'fql_read_info': (_I, [_VP, C.POINTER(_F)]),
+    'fql_synchronize': (_I, [_VP, C.POINTER(_I)]),
     'fql_stats': (_I, [_VP, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)]),
     'fql_stream': (_VP, [_VP]),
 }

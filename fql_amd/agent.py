@@ -350,6 +350,14 @@ class FQLAgent:
         self._check(self._lib.fql_read_info(self._h, buf))
         return {k: float(buf[i]) for i, k in enumerate(INFO_KEYS)}
 
+    def synchronize(self) -> str:
+        """Host wait for every update enqueued so far (jax.block_until_ready(agent)): the engine's HIP stream and the hardware queues of
+        its own that stream-less updates run on, which torch.cuda.synchronize() does not see.  Returns where the last update ran:
+        'aql' (the engine's own queues) or 'graph' (a captured graph on a HIP stream)."""
+        m = C.c_int(0)
+        self._check(self._lib.fql_synchronize(self._h, C.byref(m)))
+        return 'aql' if m.value else 'graph'
+
     def total_loss(self, batch, grad_params=None, rng=None, noise: Optional[Dict[str, Any]] = None):
         """agents/fql.py:94-111 with grad_params=None (the validation probe, main.py:284)."""
         if grad_params is not None:

@@ -16,6 +16,7 @@
 #include "fql_aux.h"
 #include "fql_xchain.h"
 #include <hip/hip_ext.h>
+#include "fql_aql.h"
 
 #include <algorithm>
 #include <atomic>
@@ -307,6 +308,16 @@ struct fql_engine {
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
     bool split_begun = false;   // the pending update was begun by launch_split (ev_c marks the end of lane 0's pre-join part)
     bool began = false;
+    // the single-GPU update as AQL packets on the engine's own HSA queues (fql_aql.h); everything else stays on HIP streams
+    AqlRuntime aql;
+    AqlProgram aql_full;
+    std::vector<AqlDispatch>* aql_rec = nullptr;   // issue() records instead of launching while this is set
+    bool last_update_aql = false;
+    bool hip_dirty = true;                         // HIP work may be pending on the engine's stream: drain it before the next AQL submit
+    void aql_drain() {                             // every AQL update submitted so far has finished (host wait)
+        if (!aql.up) return;
+        try { aql.drain(); } catch (const AqlError& e) { throw HipError{e.msg}; }
+    }
 
     // dataset
     float *ds_obs = nullptr, *ds_act = nullptr, *ds_rew = nullptr, *ds_mask = nullptr, *ds_nobs = nullptr;
@@ -1795,9 +1806,28 @@ struct fql_engine {
     // Per-launch profiling (fql_profile_update): when set, the next launch carries these two events ON ITS DISPATCH
     // (hipExtLaunchKernelGGL): their elapsed time is the dispatch's own begin-to-end time, the quantity a rocprofv3 kernel trace reports.
     hipEvent_t prof_a = nullptr, prof_b = nullptr;
+    template <typename... Pm, typename... A>
+    void aql_record(void (*k)(Pm...), dim3 g, dim3 b, size_t l, A&&... a) {
+        AqlDispatch d;
+        d.fn = (const void*)k;
+        d.grid[0] = g.x; d.grid[1] = g.y; d.grid[2] = g.z;
+        d.block[0] = b.x; d.block[1] = b.y; d.block[2] = b.z;
+        d.lds = (uint32_t)l;
+        size_t off = 0;
+        auto put = [&](auto v) {   // kernarg layout: every argument at its natural alignment
+            using T = decltype(v);
+            off = (off + alignof(T) - 1) & ~(alignof(T) - 1);
+            d.args.resize(off + sizeof(T));
+            std::memcpy(d.args.data() + off, &v, sizeof(T));
+            off += sizeof(T);
+        };
+        (put(static_cast<Pm>(a)), ...);
+        aql_rec->push_back(std::move(d));
+    }
 #define FQL_LAUNCH(k, g, b, l, st, ...)                                                          \
     do {                                                                                          \
-        if (prof_a) hipExtLaunchKernelGGL(k, g, b, (std::uint32_t)(l), st, prof_a, prof_b, 0u, __VA_ARGS__); \
+        if (aql_rec) aql_record(k, g, b, (size_t)(l), __VA_ARGS__);                               \
+        else if (prof_a) hipExtLaunchKernelGGL(k, g, b, (std::uint32_t)(l), st, prof_a, prof_b, 0u, __VA_ARGS__); \
         else hipLaunchKernelGGL(k, g, b, l, st, __VA_ARGS__);                                     \
     } while (0)
     void issue(const Launch& L, hipStream_t s, int tl) {
@@ -2104,6 +2134,100 @@ struct fql_engine {
                 HIP_CHECK(hipStreamWaitEvent(s0, pr.ev_join[l], 0));
             }
         HIP_CHECK(hipGetLastError());
+    }
+
+    // The program as AQL packet templates for the engine's own HSA queues (fql_aql.h): one queue per lane, the barrier bit inside a lane,
+    // completion signal -> barrier-AND packet across lanes.  Left off (ap.ok = false, the captured graph runs) when the HSA runtime does not
+    // come up or FQL_AQL=0.
+    void build_aql(Program& pr, AqlProgram& ap) {
+        static const bool off = getenv("FQL_AQL") && atoi(getenv("FQL_AQL")) == 0;
+        static const bool trace_a = getenv("FQL_TRACE") != nullptr;
+        ap = AqlProgram{};
+        if (off || visual) return;   // (visual updates gather their frames with HIP launches in front of the program and are device-bound anyway)
+        void* kargs = nullptr;
+        try {
+            if (!aql.up && aql.why.empty()) aql.init(device, (const void*)&fql_create);
+            if (!aql.up) throw AqlError{aql.why};
+            std::vector<AqlDispatch> rec;
+            aql_rec = &rec;
+            try { for (const Launch& L : pr.launches) issue(L, nullptr, -1); } catch (...) { aql_rec = nullptr; throw; }
+            aql_rec = nullptr;
+            const size_t n = pr.launches.size();
+            if (rec.size() != n) throw AqlError{"a launch did not record exactly one dispatch"};
+            std::vector<const AqlKernelInfo*> ki(n);
+            std::vector<size_t> koff(n);
+            size_t tot = 0;
+            for (size_t i = 0; i < n; ++i) {
+                ki[i] = &aql.kernel(rec[i].fn);
+                if (ki[i]->kernarg_size < rec[i].args.size()) throw AqlError{"recorded arguments exceed the kernel's kernarg segment"};
+                koff[i] = tot;
+                tot += ((size_t)ki[i]->kernarg_size + 63) & ~(size_t)63;
+            }
+            std::vector<uint8_t> host(tot);
+            for (size_t i = 0; i < n; ++i) AqlRuntime::fill_kernarg(host.data() + koff[i], rec[i], *ki[i]);
+            HIP_CHECK(hipMalloc(&kargs, tot));
+            HIP_CHECK(hipMemcpy(kargs, host.data(), tot, hipMemcpyHostToDevice));
+            std::vector<int> sig(n, AQL_SIG_NONE);
+            int nsig = 0;
+            bool used[FQL_AQL_LANES] = {};
+            for (const Launch& L : pr.launches) {
+                if (L.lane < 0 || L.lane >= FQL_AQL_LANES) throw AqlError{"lane out of range"};
+                used[L.lane] = true;
+                for (int w : L.waits) if (sig[w] == AQL_SIG_NONE) sig[w] = nsig++;
+            }
+            if (!used[0]) throw AqlError{"program without a lane 0"};
+            int endsig[FQL_AQL_LANES];
+            for (int l = 1; l < FQL_AQL_LANES; ++l) endsig[l] = used[l] ? nsig++ : AQL_SIG_NONE;
+            // fences between packets: agent scope both ways, as the HIP runtime sets them for kernels of one stream.  Measured (profiles/r03_aql.txt): system scope
+            // 416 us per update, agent 355, acquire dropped 336 with the same results over 1300 updates (the invalidate is then left to eviction: not a guarantee,
+            // not shipped), release dropped 332 and wrong.
+            constexpr int AG = HSA_FENCE_SCOPE_AGENT, SY = HSA_FENCE_SCOPE_SYSTEM, NO = HSA_FENCE_SCOPE_NONE;
+            for (int l = 1; l < FQL_AQL_LANES; ++l)
+                if (used[l]) {   // the previous update has finished on every lane
+                    AqlPacket b = AqlRuntime::barrier_packet(false, NO, NO);
+                    b.deps[0] = AQL_SIG_PREV_DONE;
+                    ap.lane[l].push_back(b);
+                }
+            bool first[FQL_AQL_LANES] = {true, true, true, true};
+            for (size_t i = 0; i < n; ++i) {
+                const Launch& L = pr.launches[i];
+                for (size_t w0 = 0; w0 < L.waits.size(); w0 += 5) {
+                    AqlPacket b = AqlRuntime::barrier_packet(false, NO, NO);
+                    for (size_t j = 0; j < 5 && w0 + j < L.waits.size(); ++j) b.deps[j] = sig[L.waits[w0 + j]];
+                    ap.lane[L.lane].push_back(b);
+                }
+                AqlPacket k = AqlRuntime::kernel_packet(rec[i], *ki[i], (uint64_t)(uintptr_t)kargs + koff[i], true, first[L.lane] ? SY : AG, AG);
+                first[L.lane] = false;
+                k.complete = sig[i];
+                ap.lane[L.lane].push_back(k);
+            }
+            for (int l = 1; l < FQL_AQL_LANES; ++l)
+                if (used[l]) {
+                    AqlPacket b = AqlRuntime::barrier_packet(true, NO, AG);
+                    b.complete = endsig[l];
+                    ap.lane[l].push_back(b);
+                }
+            {
+                AqlPacket b = AqlRuntime::barrier_packet(true, NO, SY);
+                int j = 0;
+                for (int l = 1; l < FQL_AQL_LANES; ++l) if (used[l]) b.deps[j++] = endsig[l];
+                b.complete = AQL_SIG_DONE;
+                ap.lane[0].push_back(b);
+            }
+            aql.ensure_signals(nsig);
+            for (int l = 0; l < FQL_AQL_LANES; ++l) if (used[l]) aql.ensure_queue(l);
+            ap.nsig = nsig;
+            ap.kernargs = kargs;
+            ap.ok = true;
+            if (trace_a) fprintf(stderr, "[fql] AQL program: %zu launches, packets per lane %zu %zu %zu %zu, %d signals, %zu bytes of kernargs\n", n,
+                                 ap.lane[0].size(), ap.lane[1].size(), ap.lane[2].size(), ap.lane[3].size(), nsig, tot);
+        } catch (const AqlError& e) {
+            aql_rec = nullptr;
+            if (kargs) hipFree(kargs);
+            ap = AqlProgram{};
+            if (aql.why.empty()) aql.why = e.msg;
+            if (trace_a || getenv("FQL_AQL")) fprintf(stderr, "[fql] AQL path off: %s\n", e.msg.c_str());
+        }
     }
 
     void capture(Program& pr) {
@@ -2627,6 +2751,9 @@ struct fql_engine {
         free_program(prog_loss);
         free_program(prog_split);
         free_program(prog_full);
+        aql_drain();
+        if (aql_full.kernargs) { hipFree(aql_full.kernargs); }
+        aql_full = AqlProgram{};
         use_xchain = false; xsync = nullptr; xvp = nullptr; x_stamps = nullptr;
         free_split();
         for (void* p : ws_allocs) hipFree(p);
@@ -2763,6 +2890,8 @@ struct fql_engine {
             FQL_TR("scheduled full");
             capture(prog_full);
             FQL_TR("captured full");
+            build_aql(prog_full, aql_full);
+            FQL_TR(aql_full.ok ? "AQL packets built" : "AQL path off");
         }
         {
             split_build = true;
@@ -2790,9 +2919,12 @@ struct fql_engine {
     void drain_staging(hipStream_t s) {
         if (staged_host) { HIP_CHECK(hipStreamSynchronize(s)); staged_host = false; }
     }
+    // HIP is about to write a buffer the update reads: updates still on the AQL queues must have finished, and the next AQL submit must wait for the stream
+    void hip_touch() { aql_drain(); hip_dirty = true; }
     const float* stage(const float* p, float* staging, size_t n, hipStream_t s) {
         if (!p) return nullptr;
         if (is_device_ptr(p)) return p;
+        hip_touch();
         HIP_CHECK(hipMemcpyAsync(staging, p, n * sizeof(float), hipMemcpyHostToDevice, s));
         staged_host = true;
         return staging;
@@ -2802,6 +2934,7 @@ struct fql_engine {
         SrcDesc* slot = &h_src_ring[src_ring_pos];
         src_ring_pos = (src_ring_pos + 1) % 64;
         *slot = d;
+        hip_touch();
         HIP_CHECK(hipMemcpyAsync(d_src, slot, sizeof d, hipMemcpyHostToDevice, s));
         h_src_shadow = d;
         src_valid = true;
@@ -2849,6 +2982,7 @@ struct fql_engine {
         if (idx) {
             if (is_device_ptr(idx)) d.idx = idx;
             else {
+                hip_touch();
                 HIP_CHECK(hipMemcpyAsync(in_idx, idx, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, s));
                 staged_host = true;
                 d.idx = in_idx;
@@ -2865,6 +2999,7 @@ struct fql_engine {
     const int64_t* stage_two_idx(const int64_t* a, const int64_t* b, int split, int64_t* dst, hipStream_t s) {
         if (!a && !b) return nullptr;
         if (!a || !b) throw Invalid{"balanced sampling: give both index arrays or neither"};
+        hip_touch();
         HIP_CHECK(hipMemcpyAsync(dst, a, (size_t)split * sizeof(int64_t), hipMemcpyDefault, s));
         HIP_CHECK(hipMemcpyAsync(dst + split, b, (size_t)(B - split) * sizeof(int64_t), hipMemcpyDefault, s));
         if (!is_device_ptr(a) || !is_device_ptr(b)) staged_host = true;
@@ -2938,6 +3073,7 @@ struct fql_engine {
     }
     void finish_info(float* info, int n, hipStream_t s) {
         if (!info) return;
+        hip_touch();
         if (is_device_ptr(info)) {
             HIP_CHECK(hipMemcpyAsync(info, &d_state->info[0], n * sizeof(float), hipMemcpyDeviceToDevice, s));
         } else {
@@ -3033,8 +3169,13 @@ struct fql_engine {
 // ================================================================================================
 // C ABI
 // ================================================================================================
-#define FQL_TRY(h, ...)                                    \
+// FQL_TRY: every entry point that may use HIP on the engine's buffers - updates still on the engine's AQL queues finish first.
+// FQL_TRY_FAST: the update entry points that can go to those queues themselves (run_full decides).
+#define FQL_TRY(h, ...) FQL_TRY_(h, (h)->hip_touch(), __VA_ARGS__)
+#define FQL_TRY_FAST(h, ...) FQL_TRY_(h, (void)0, __VA_ARGS__)
+#define FQL_TRY_(h, pre, ...)                              \
     try {                                                  \
+        pre;                                               \
         __VA_ARGS__;                                       \
         return FQL_OK;                                     \
     } catch (const Invalid& e) {                           \
@@ -3193,9 +3334,11 @@ int fql_create(const fql_config* cfg, uint64_t seed, fql_handle* out) {
 int fql_destroy(fql_handle h) {
     if (!h) return FQL_OK;
     h->stop_workers();
+    try { h->aql_drain(); } catch (...) {}
     if (h->stream) hipStreamSynchronize(h->stream);
     hipDeviceSynchronize();
     h->free_workspace();
+    h->aql.shutdown();
     for (auto& kv : h->evals) {
         for (void* p : kv.second->allocs) hipFree(p);
     }
@@ -3307,6 +3450,22 @@ static void run_program(fql_handle h, Program& pr, hipStream_t s) {
     else HIP_CHECK(hipGraphLaunch(pr.exec, s));
 }
 
+// The whole update (prog_full).  The caller left the stream to the engine: pre-built AQL packets on the engine's own queues (fql_aql.h; the
+// stream is drained first if HIP work may be pending on it).  Otherwise, or when that path is off: the captured graph on `s`.
+static void run_full(fql_handle h, hipStream_t s, bool own_stream) {
+    static const int no_graph = getenv("FQL_NO_GRAPH") ? atoi(getenv("FQL_NO_GRAPH")) : 0;
+    if (own_stream && h->aql_full.ok && !no_graph && h->prog_full.exec) {
+        if (h->hip_dirty) { HIP_CHECK(hipStreamSynchronize(s)); h->hip_dirty = false; }
+        try { h->aql.submit(h->aql_full); } catch (const AqlError& e) { throw HipError{e.msg}; }
+        h->last_update_aql = true;
+        return;
+    }
+    h->last_update_aql = false;
+    h->hip_touch();
+    if (h->prog_full.exec) run_program(h, h->prog_full, s);
+    else { run_program(h, h->prog_fwdbwd, s); run_program(h, h->prog_opt, s); }
+}
+
 int fql_update_begin(fql_handle h, const float* obs, const float* act, const float* rew, const float* mask,
                      const float* nobs, int batch_size, const fql_noise* noise, void* stream) {
     if (!h) return FQL_E_INVALID;
@@ -3331,10 +3490,10 @@ int fql_update_end(fql_handle h, float* info13, void* stream) {
 int fql_update(fql_handle h, const float* obs, const float* act, const float* rew, const float* mask, const float* nobs,
                int batch_size, const fql_noise* noise, float* info13, void* stream) {
     if (h && h->prog_full.exec && !h->began) {
-        FQL_TRY(h, {
+        FQL_TRY_FAST(h, {
             hipStream_t s = pick(h, stream);
             h->source_from_batch(obs, act, rew, mask, nobs, batch_size, noise, 1, s);
-            run_program(h, h->prog_full, s);
+            run_full(h, s, stream == nullptr);
             h->finish_info(info13, FQL_NUM_INFO, s);
         });
     }
@@ -3549,11 +3708,11 @@ int fql_update_balanced(fql_handle h, const int64_t* idx_dataset, const int64_t*
                         const fql_noise* noise, float* info13, void* stream) {
     if (!h) return FQL_E_INVALID;
     if (h->began) { h->err = "fql_update_balanced between fql_update_begin and fql_update_end"; return FQL_E_STATE; }
-    FQL_TRY(h, {
+    FQL_TRY_FAST(h, {
         hipStream_t s = pick(h, stream);
+        if (h->visual) h->hip_touch();
         h->source_balanced(idx_dataset, idx_replay, crop_froms, batch_size, noise, s);
-        if (h->prog_full.exec) run_program(h, h->prog_full, s);
-        else { run_program(h, h->prog_fwdbwd, s); run_program(h, h->prog_opt, s); }
+        run_full(h, s, stream == nullptr);
         h->finish_info(info13, FQL_NUM_INFO, s);
     });
 }
@@ -3610,10 +3769,10 @@ int fql_update_from_dataset(fql_handle h, const int64_t* idx, int batch_size, in
                             float* info13, void* stream) {
     if (h && h->visual) return fql_update_from_frames(h, idx, nullptr, batch_size, lo, hi, noise, info13, stream);
     if (h && h->prog_full.exec && !h->began) {
-        FQL_TRY(h, {
+        FQL_TRY_FAST(h, {
             hipStream_t s = pick(h, stream);
             h->source_from_dataset(idx, batch_size, lo, hi, noise, s);
-            run_program(h, h->prog_full, s);
+            run_full(h, s, stream == nullptr);
             h->finish_info(info13, FQL_NUM_INFO, s);
         });
     }
@@ -3646,6 +3805,15 @@ int fql_info_wait(fql_handle h, uint64_t ticket, float* info13_host) {
             HIP_CHECK(hipMemcpy(&e, h->pec_epoch + h->pec_teams, sizeof e, hipMemcpyDeviceToHost));
             if (e) throw HipError{"persistent Euler chain: a team hand-off timed out (that update and every later one were not applied)"};
         }
+    });
+}
+
+int fql_synchronize(fql_handle h, int* mode) {
+    if (!h) return FQL_E_INVALID;
+    if (mode) *mode = h->last_update_aql ? 1 : 0;
+    FQL_TRY(h, {
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->hip_dirty = false;
     });
 }
 

@@ -250,6 +250,11 @@ int fql_update_balanced(fql_handle h, const int64_t* idx_dataset, const int64_t*
 
 /* Blocking read of the info of the last update (the reference reads lazily at log time, main.py:276). */
 int fql_read_info(fql_handle h, float* info13_host);
+/* Host wait for everything the engine has enqueued: its HIP stream AND the hardware queues of its own that updates with stream = NULL
+ * run on (a hipStreamSynchronize / hipDeviceSynchronize of the caller does not see those queues; every other entry point of this header
+ * waits for them by itself before it touches the engine's buffers).  `mode` (out, may be NULL): 1 if the last fql_update* call went to
+ * the engine's own queues, 0 if it ran as a captured graph on a stream.  (jax.block_until_ready on the agent, main.py:216.) */
+int fql_synchronize(fql_handle h, int* mode);
 /* Lazy infos, as the reference's `agent, info = agent.update(batch)` returns them (device scalars nobody waits for until they are
  * logged, main.py:216,276): fql_info_enqueue, called right after an update on the same stream, snapshots that update's 13 scalars
  * asynchronously (no host synchronisation) and returns a ticket; fql_info_wait blocks until the snapshot has landed and copies it
