@@ -159,11 +159,11 @@ def pmc_counters(fname, kernel):
 def short_window(agent, B, steps, warmup, torch):
     for _ in range(warmup):
         agent.update_from_dataset(B)
-    torch.cuda.synchronize(); agent.read_info()
+    agent.synchronize(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         agent.update_from_dataset(B)
-    agent.read_info(); torch.cuda.synchronize()
+    agent.synchronize(); torch.cuda.synchronize()
     return time.perf_counter() - t0
 
 
@@ -369,7 +369,10 @@ def main():
         else:
             agent.update_from_dataset(B)      # the engine's own stream; no host synchronisation inside the window
 
+    dispatch = []
+
     def fence():
+        dispatch.append(agent.synchronize())  # the engine's own hardware queues (stream-less updates) are not torch's: wait for them first
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -407,6 +410,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt * 1e3 / args.steps, 5),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'bf16x3', 'data': 'synthetic',
             'config': {'workload': work, 'parallelism': f'dp{world}', 'samples_per_s': round(steps_per_s * world * B, 1)},
+            'dispatch': ('AQL packets on the engine\'s own HSA queues (fql_amd/csrc/fql_aql.h)' if dispatch[-1] == 'aql' else 'captured hipGraph on HIP streams'),
             'rccl_ranks': (dist.get_world_size() if dist is not None else 1), 'backend': (dist.get_backend() if dist is not None else None),
             'device': torch.cuda.current_device(), 'data_parallel_step': dp_mode,
             'whole_update': {'flop': flop_per_step, 'wall_us': round(step_us_wall, 3), 'achieved_tflops': round(whole, 3),
