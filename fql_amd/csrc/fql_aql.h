@@ -314,6 +314,13 @@ struct AqlRuntime {
                 for (int j = 1; j < 16; ++j) slot[j] = w[j];
                 __atomic_store_n(slot, w[0], __ATOMIC_RELEASE);   // the header last: the packet processor may take the packet from here on
             }
+            // one doorbell per contiguous run: a batch that wraps the ring is rung in two parts (a queue intercepted by a tool - rocprofv3's kernel
+            // trace - was handed the whole batch as one array and read past the end of the ring: SIGSEGV on the first wrap, 96 updates in)
+            const uint64_t to_end = Q->size - (idx & mask);
+            if (n > to_end) {
+                hsa_queue_store_write_index_relaxed(Q, idx + to_end);
+                hsa_signal_store_screlease(Q->doorbell_signal, (hsa_signal_value_t)(idx + to_end - 1));
+            }
             hsa_queue_store_write_index_relaxed(Q, idx + n);
             hsa_signal_store_screlease(Q->doorbell_signal, (hsa_signal_value_t)(idx + n - 1));
         }

@@ -2165,7 +2165,7 @@ struct fql_engine {
             }
             std::vector<uint8_t> host(tot);
             for (size_t i = 0; i < n; ++i) AqlRuntime::fill_kernarg(host.data() + koff[i], rec[i], *ki[i]);
-            HIP_CHECK(hipMalloc(&kargs, tot));
+            HIP_CHECK(hipMalloc(&kargs, tot));   // device memory: with the blocks in host memory every launch starts 0.7 us later (417 us per update against 355)
             HIP_CHECK(hipMemcpy(kargs, host.data(), tot, hipMemcpyHostToDevice));
             std::vector<int> sig(n, AQL_SIG_NONE);
             int nsig = 0;
