@@ -356,7 +356,6 @@ struct fql_engine {
     unsigned* xsync = nullptr;      // [17][32] words: arrival flags, tickets (zeroed by the prep launch), sticky error word
     float* xvp = nullptr;           // head partials [32][B][16]
     size_t x_lds = 0;
-    bool x_wlds = false;            // the chain's hidden kernels resident in LDS (else streamed into registers behind each arrival)
     unsigned long long* x_stamps = nullptr;
 
     int64_t launches_per_update = 0;
@@ -1225,9 +1224,9 @@ struct fql_engine {
     // The whole chain as ONE persistent XCD-resident launch (fql_xchain.h): 8 row blocks x 32 column slices, activations exchanged through
     // each XCD's own L2, hidden kernels resident in LDS.
     bool xchain_eligible() const {
-        // opt-in (FQL_XCHAIN=1).  Measured at B = 256, H = 512: the chain alone 136 us in this ONE launch against ~170 us as 30 launches, but the update
-        // 383 us against 352 us: the persistent workgroup holds 115 KB of every CU's LDS for the hidden kernels, the side lanes' workgroups beside it
-        // drop from three or four per CU to one, and they end the update (profiles/r03_xcd_resident.txt).
+        // opt-in (FQL_XCHAIN=1).  Measured at B = 256, H = 512 (profiles/r03_xcd_resident.txt): the update takes 352-359 us with this ONE launch in place of
+        // the chain's 30 against 344-345 us with the launches (each member re-reads its XCD's whole activation panel and its slice of the layer's kernel
+        // every phase: 3 MB through an XCD's L2 per phase).
         if (!getenv("FQL_XCHAIN") || atoi(getenv("FQL_XCHAIN")) == 0) return false;
         if (visual || cfg.precision != 0 || cfg.actor_layer_norm || cfg.act_dim > 15) return false;
         if (num_cus != XCH_NGRP * XCH_NMEM || B % 128 != 0 || B / 128 > XCH_MAXRT) return false;
@@ -1237,9 +1236,7 @@ struct fql_engine {
         const int H = n.layers[0].out;
         if (H % 16 || H > 512 || n.layers[0].in_p > 128 || n.layers[nh].out_p != 16) return false;
         for (int l = 0; l < nh; ++l) if (n.layers[l].out != H || n.layers[l].out_p != H) return false;
-        // beside this kernel's workgroup a CU must still take a side-lane workgroup: <= 116 KB of its 160 KB of LDS
-        if ((size_t)FQL_XCHAIN_LDS_FLOATS(nh - 1, H, true) * sizeof(float) > 116 * 1024) return false;
-        return true;
+        return use_chain;   // (the kernel reads the fragment-major copies the chain launches read)
     }
     void emit_euler_xcd(Program& pr) {
         const Net& n = nets[NET_BC];
@@ -1252,19 +1249,19 @@ struct fql_engine {
         a.od = cfg.obs_dim; a.ad = cfg.act_dim; a.ap = pad16(cfg.act_dim); a.in_p = n.in_p(); a.fs = cfg.flow_steps;
         a.x_e0 = X_eu; a.x_eu = X_eu;   // (C0 masks the action / t rows of the first kernel: the Euler input serves as its observation-only input too)
         a.w0 = P + n.layers[0].w; a.b0 = P + n.layers[0].b;
-        for (int l = 1; l < nh; ++l) { a.w[l - 1] = P + n.layers[l].w; a.b[l - 1] = P + n.layers[l].b; }
+        for (int l = 1; l < nh; ++l) { a.b[l - 1] = P + n.layers[l].b; a.wf[l - 1] = wf_bc[l - 1]; }
         a.w4 = P + n.layers[nh].w; a.b4 = P + n.layers[nh].b;
         a.hc[0] = p_eu.g[0]; a.hc[1] = p_eu.g[1];
         a.vp = xvp; a.tgt = tgt; a.sync = xsync;
         a.stamps = x_stamps;
         op.reads = {X_eu};
         for (const Layer& L : n.layers) op.reads.push_back(P + L.w);
+        for (float* w : wf_bc) op.reads.push_back(w);
         op.writes = {tgt, xvp, p_eu.g[0], p_eu.g[1]};
         push(pr, op);
     }
     // refresh of the fragment-major copies inside a program, behind the Adam launch that rewrites the BC flow's kernels
     void emit_wfrag(Program& pr) {
-        if (use_xchain) return;   // (nothing reads the copies: the persistent chain takes the kernels as flax stores them)
         if (!use_chain) return;
         const Net& n = nets[NET_BC];
         Op op{};
@@ -1496,7 +1493,6 @@ struct fql_engine {
                         const int ncu = std::max(1, num_cus);
                         const double m64 = 2.0 * ((t64 + ncu - 1) / ncu) + other / ncu, m32 = 1.0 * ((2 * t64 + ncu - 1) / ncu) + other / ncu;
                         if (t64 > 0 && m32 < m64 && !wide_tiles) nj = 1;
-                        if (use_xchain && x_wlds) nj = 1;   // 36 KB of LDS: fits beside the persistent chain's workgroup (115 KB) on a CU, 32 x 64 tiles (53 KB) do not
                         if (nj_env == 1 || nj_env == 2) nj = nj_env;
                     }
                     for (const Op* o : sel) {
@@ -1970,8 +1966,7 @@ struct fql_engine {
                 FQL_LAUNCH(fql_wfrag_kernel, dim3(wfrag_grid), dim3(FQL_THREADS), 0, s, (const WfragTask*)d_wfrag, wfrag_n, tl);
                 break;
             case OP_XCHAIN:   // one workgroup per CU: 8 XCDs x 32 members
-                if (x_wlds) FQL_LAUNCH(fql_xchain_kernel<true>, dim3(XCH_NGRP * XCH_NMEM), dim3(256), x_lds, s, L.op.xchain);
-                else FQL_LAUNCH(fql_xchain_kernel<false>, dim3(XCH_NGRP * XCH_NMEM), dim3(256), x_lds, s, L.op.xchain);
+                FQL_LAUNCH(fql_xchain_kernel, dim3(XCH_NGRP * XCH_NMEM), dim3(256), x_lds, s, L.op.xchain);
                 break;
             case OP_ADAM: {
                 AdamArgs a{P, G, Mu, Nu, P + n_train, d_chunks, d_state, d_partials, L.op.adam_c0, (int)critic_size, cfg.lr, cfg.tau, tl,
@@ -2154,6 +2149,7 @@ struct fql_engine {
             aql_rec = nullptr;
             const size_t n = pr.launches.size();
             if (rec.size() != n) throw AqlError{"a launch did not record exactly one dispatch"};
+
             std::vector<const AqlKernelInfo*> ki(n);
             std::vector<size_t> koff(n);
             size_t tot = 0;
@@ -2388,7 +2384,7 @@ struct fql_engine {
         const bool lanes3 = lanes3_env && !visual && !split_build;
         const int fill_lane = lanes3 ? 2 : 1;
         if (!split_build) fill_lane_full = fill_lane;
-        wide_tiles = lanes3 && !(use_xchain && x_wlds);   // (beside the persistent chain's workgroup a CU has ~45 KB of LDS left: 32 x 32 side tiles fit, 32 x 64 do not)
+        wide_tiles = lanes3;
         place("os", 1, true);
         // one-step actor on [next_obs|eps1 ; obs|z ; obs|eps2]  (agents/fql.py:25,65,82)
         emit_forward(pr, p_os, with_grads, GF_OS_SCATTER, X_ct, X_c2);
@@ -2825,13 +2821,11 @@ struct fql_engine {
         use_xchain = xchain_eligible();
         if (use_xchain) {
             const Net& nb = nets[NET_BC];
-            x_wlds = true;   // (false: kernels streamed into registers behind each arrival, 16 KB of LDS - measured 319 us for the chain against 136)
-            x_lds = (size_t)FQL_XCHAIN_LDS_FLOATS(nb.nl() - 2, nb.layers[0].out_p, x_wlds) * sizeof(float);
+            x_lds = (size_t)FQL_XCHAIN_LDS_FLOATS * sizeof(float);
             int per_cu = 0;   // every workgroup waits for its XCD's other 31: all 256 must be resident, one per CU
-            const void* kf = x_wlds ? (const void*)fql_xchain_kernel<true> : (const void*)fql_xchain_kernel<false>;
+            const void* kf = (const void*)fql_xchain_kernel;
             hipError_t oe = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x_lds);
-            if (oe == hipSuccess) oe = x_wlds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fql_xchain_kernel<true>, 256, x_lds)
-                                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fql_xchain_kernel<false>, 256, x_lds);
+            if (oe == hipSuccess) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fql_xchain_kernel, 256, x_lds);
             if (oe != hipSuccess || per_cu < 1) {
                 (void)hipGetLastError();
                 use_xchain = false;

@@ -6,9 +6,11 @@
 // an XCD take that block through every layer of every step: a layer is split over the 32 members by output columns (16 each at H = 512), a
 // member needs the whole [rows x H] activation panel of its block, and the panel is exchanged through THAT XCD's L2 only - plain stores
 // (they stay in the L2), sc1 loads (they bypass the reader's L1), tile-major so that every wave load / store is one contiguous KB.  Rows never
-// meet across XCDs (the chain is row-wise), so there is no cross-XCD traffic and no agent-scope fence inside the launch.  Each member keeps
-// its 16 columns of every hidden kernel in LDS for the whole launch (3 x 32 KB at H = 512), its rows of the action head and of layer 0's
-// rank-16 update and its tile of C0 = obs W0[obs rows] + b0 in registers: a phase loads nothing but the activation panel.
+// meet across XCDs (the chain is row-wise), so there is no cross-XCD traffic and no agent-scope fence inside the launch.  Each member streams
+// its 16 columns of the next hidden kernel into registers right behind its arrival (eight 16-byte loads a lane from the fragment-major copies
+// fql_wfrag_kernel keeps, in flight while it waits for the others) and keeps its rows of the action head and of layer 0's rank-16 update and its
+// tile of C0 = obs W0[obs rows] + b0 in registers; the launch takes 16 KB of LDS.  (With the kernels resident in LDS instead - 3 x 32 KB a
+// member - the chain alone is faster, 136 us, but a CU then has 45 KB of LDS left and the update takes 393 us against 352 for this form.)
 //
 // Synchronisation: member m of XCD g stores its phase count into word m of that XCD's flag line (a plain store: L2), a waiting workgroup polls
 // the 32 words with one 32-lane sc1 load.  (An agent-scope atomic counter executes at the memory side, not in the L2: measured 1.4 us from the
@@ -30,13 +32,13 @@
 
 struct XChainArgs {
     int B, R, RT;              // batch, rows per XCD, 16-row tiles per XCD
-    int H, nl;                 // hidden width of the BC flow; hidden kernels 1 .. nl (LDS resident: nl * H * 64 bytes)
+    int H, nl;                 // hidden width of the BC flow; hidden kernels 1 .. nl
     int od, ad, ap, in_p, fs;
     const float* x_e0;         // [B, in_p] (obs | 0): C0's input
     const float* x_eu;         // [B, in_p] (obs | z | 0): initial actions
     const float* w0;           // first kernel [in_p][H]
     const float* b0;
-    const float* w[7];         // hidden kernels 1 .. nl, [H][H]
+    const float* wf[7];        // hidden kernels 1 .. nl as fragment-major copies [H/4][H][4] (fql_wfrag_kernel)
     const float* b[7];
     const float* w4;           // action head [H][ap]
     const float* b4;
@@ -90,11 +92,7 @@ __device__ __forceinline__ void xc_arrive(XChCtx& c) {
 // offset (floats) of lane (r, q)'s 16 bytes of tile (row base rb, column tile ct) of a tile-major [rows, 16 ntn] tensor
 __device__ __forceinline__ unsigned xc_toff(int lane, int rb, int ct, int ntn) { return (unsigned)((((rb >> 4) * ntn + ct) << 8) + (lane << 2)); }
 
-// WLDS: the hidden kernels live in LDS for the whole launch (96 KB at H = 512: fastest alone on the chip, but it leaves a CU ~45 KB of LDS for the
-// side lanes' workgroups); else each layer's fragment is loaded into registers right behind the previous phase's arrival - the loads do not depend on
-// the barrier, so their latency hides in the wait - and the kernel takes 16 KB of LDS.
-template <bool WLDS>
-__global__ __launch_bounds__(256, 4) void fql_xchain_kernel(const XChainArgs a) {
+__global__ __launch_bounds__(256, 3) void fql_xchain_kernel(const XChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float xch_lds[];
     XChCtx c;
     c.lane = threadIdx.x & 63; c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -106,7 +104,6 @@ __global__ __launch_bounds__(256, 4) void fql_xchain_kernel(const XChainArgs a) 
     f32x4* red = reinterpret_cast<f32x4*>(xch_lds);                 // [4 waves][2 tiles][64] float4
     float* alds = xch_lds + 8 * 64 * 4;                               // [R][16] current actions (+ t column)
     unsigned* misc = reinterpret_cast<unsigned*>(alds + XCH_MAXRT * 16 * 16);
-    f32x4* wl = reinterpret_cast<f32x4*>(misc + 16);                  // hidden kernels: [nl][H / 16][64] float4, fragment-major
     c.dead = misc + 1;
     if (threadIdx.x == 0) {
         misc[0] = __hip_atomic_fetch_add((FQL_GAS unsigned*)(a.sync + 32 * (8 + c.g)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -121,17 +118,6 @@ __global__ __launch_bounds__(256, 4) void fql_xchain_kernel(const XChainArgs a) 
     const int H = a.H, J = H >> 4, n0 = 16 * c.member, RT = a.RT, R = a.R;
     const bool active = n0 < H;
     const int rbase = c.g * R;
-    // this member's 16 output columns of every hidden kernel, fragment-major: lane (n, q) of slice j holds W[16 j + 4 q + t][n0 + n], t = 0..3
-    if (active && WLDS)
-        for (int l = 0; l < a.nl; ++l)
-            for (int i = threadIdx.x; i < J * 64; i += 256) {
-                const int j = i >> 6, ln = i & 63, rr = ln & 15, qq = ln >> 4;
-                f32x4 v;
-                const float* p = a.w[l] + (size_t)(16 * j + 4 * qq) * H + n0 + rr;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = ldg(p + (size_t)t * H);
-                wl[((size_t)l * J + j) * 64 + ln] = v;
-            }
     // rows od .. od + 15 of the first kernel (the action block, t, zero padding) and this member's 16 rows of the action head, as first MFMA operands
     f32x4 w0f, w4f;
 #pragma unroll
@@ -201,16 +187,12 @@ __global__ __launch_bounds__(256, 4) void fql_xchain_kernel(const XChainArgs a) 
     // the fragment of hidden layer l (1-based) for this wave's K slices, from memory as flax stores it: lane (n, q) of slice j holds W[16 j + 4 q + t][n0 + n]
     f32x4 wreg[8];
     auto wfetch = [&](int l) {
-        if (WLDS || !active) return;
+        if (!active) return;
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const int j = c.wave + 4 * jj;
             wreg[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (j < J) {
-                const float* p = a.w[l - 1] + (size_t)(16 * j + 4 * c.q) * H + n0 + c.r;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) wreg[jj][t] = ldg(p + (size_t)t * H);
-            }
+            if (j < J) wreg[jj] = ldg4(a.wf[l - 1] + ((size_t)(4 * j + c.q) * H + n0 + c.r) * 4);   // W[16 j + 4 q + t][n0 + n], t = 0..3: one 16-byte load
         }
     };
 #ifdef FQL_XSTAMPS
@@ -253,7 +235,6 @@ __global__ __launch_bounds__(256, 4) void fql_xchain_kernel(const XChainArgs a) 
             if (active) {
                 const float* A = a.hc[(l - 1) & 1];
                 float* Co = a.hc[l & 1];
-                const f32x4* wf = wl + (size_t)(l - 1) * J * 64;
                 const f32x4 bv = ldg4(a.b[l - 1] + n0 + 4 * c.q);
                 for (int t0 = 0; t0 < RT; t0 += 2) {   // two row tiles per pass share each weight-fragment read; K is split over the four waves
                     const bool two = t0 + 1 < RT;
@@ -270,8 +251,7 @@ __global__ __launch_bounds__(256, 4) void fql_xchain_kernel(const XChainArgs a) 
                     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
                     for (int jj = 0; jj < 8; ++jj) {
-                        const int j = c.wave + 4 * jj;
-                        const f32x4 wv = WLDS ? (j < J ? wf[j * 64 + c.lane] : f32x4{0.f, 0.f, 0.f, 0.f}) : wreg[jj];
+                        const f32x4 wv = wreg[jj];
 #pragma unroll
                         for (int tt = 0; tt < 4; ++tt) {
                             acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[tt], av[0][jj][tt], acc[0], 0, 0, 0);
@@ -321,4 +301,4 @@ __global__ __launch_bounds__(256, 4) void fql_xchain_kernel(const XChainArgs a) 
         }
 }
 
-#define FQL_XCHAIN_LDS_FLOATS(nl, H, wlds) (8 * 64 * 4 + XCH_MAXRT * 16 * 16 + 16 + ((wlds) ? (nl) * ((H) / 16) * 64 * 4 : 0))
+#define FQL_XCHAIN_LDS_FLOATS (8 * 64 * 4 + XCH_MAXRT * 16 * 16 + 16)

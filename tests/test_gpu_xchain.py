@@ -31,7 +31,7 @@ def _run(cfg, batch, noise, params, xchain):
     return a, info, launches
 
 
-@pytest.mark.parametrize('B,H,fs', [(128, 64, 3), (256, 512, 10)])
+@pytest.mark.parametrize('B,H,fs', [(128, 256, 3), (256, 512, 10)])
 def test_xchain_update_matches_oracle_and_default_program(B, H, fs):
     od, ad = 29, 8
     cfg, ds, batch, noise = make_problem(od, ad, B, (H,) * 4, seed=3, flow_steps=fs)
