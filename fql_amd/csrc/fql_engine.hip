@@ -1430,6 +1430,24 @@ struct fql_engine {
                 readers.erase(w);
             }
         }
+        {
+            // The folds of the encoders' weight-gradient partials (27 tiny tasks, one launch per convolution level = 9 launches of ~16 us in the
+            // middle of the backward pass) are needed by nothing but their module's Adam launch: as late as possible they share one launch per module.
+            std::vector<std::vector<int>> cons(pr.ops.size());
+            for (int oi = 0; oi < (int)pr.ops.size(); ++oi)
+                for (int d : pr.ops[oi].deps) cons[d].push_back(oi);
+            for (int oi = (int)pr.ops.size() - 1; oi >= 0; --oi) {
+                Op& op = pr.ops[oi];
+                if (op.type != OP_CONV_WRED) continue;
+                int lv = 1 << 30;
+                for (int c : cons[oi]) lv = std::min(lv, pr.ops[c].level - 1);
+                if (cons[oi].empty()) {   // (the optimizer is another program: the end of this one)
+                    lv = 0;
+                    for (const Op& o2 : pr.ops) lv = std::max(lv, o2.level);
+                }
+                if (lv > op.level) op.level = lv;
+            }
+        }
         int maxlv = 0;
         for (const Op& op : pr.ops) maxlv = std::max(maxlv, op.level);
         pr.launches.clear();
@@ -1634,6 +1652,25 @@ struct fql_engine {
                         L.table = up(tb.data(), tb.size() * sizeof(ConvWredArgs));
                     }
                     L.grid = tile;
+                    pr.launches.push_back(L);
+                    continue;
+                }
+                if (ty == OP_CONV_WPREP && sel.size() > 1) {   // the encoder passes of one level refresh their LDS-layout weight copies in ONE launch
+                    int tot = 0;
+                    for (const Op* o : sel) tot += o->wprep_n;
+                    ConvWprepTask* all = (ConvWprepTask*)dalloc(owner, (size_t)tot * sizeof(ConvWprepTask) / sizeof(float) + 4);
+                    int at = 0;
+                    for (const Op* o : sel) {
+                        HIP_CHECK(hipMemcpy(all + at, o->wprep_tasks, (size_t)o->wprep_n * sizeof(ConvWprepTask), hipMemcpyDeviceToDevice));
+                        at += o->wprep_n;
+                        launch_of[o - pr.ops.data()] = (int)pr.launches.size();
+                    }
+                    Launch L;
+                    L.type = OP_CONV_WPREP;
+                    L.op = *sel[0];
+                    L.op.wprep_tasks = all;
+                    L.op.wprep_n = tot;
+                    L.lane = lane;
                     pr.launches.push_back(L);
                     continue;
                 }
