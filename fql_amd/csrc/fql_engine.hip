@@ -2524,10 +2524,10 @@ struct fql_engine {
         // Euler chain through the BC flow (fql.py:155-171): flow_steps sequential forwards
         place("eu", 0, false);
         const int fs = cfg.flow_steps;
-        // FQL_FUSE_EF=1: the last Euler step's target is finished inside the one-step head dgrad's prologue (GF_A_EULFIN: one launch less on the
-        // critical lane).  Built, parity-green (bit-identical target) and measured no faster - bf16x3 3037 -> 3018, fp32 2555 -> 2550 updates/s: the 16
-        // partial loads per element lengthen the prologue of all 256 workgroups by what the launch boundary saved - so it is opt-in.
-        constexpr bool fuse_ef_env = false;
+        // The last Euler step's target is finished inside the one-step head dgrad's prologue (GF_A_EULFIN: one launch less on the critical lane,
+        // bit-identical target).  The 16 partial loads per element lengthen the prologue of all 256 workgroups by most of what the launch boundary
+        // saves: -0.45 % per update in both orders of an in-process A/B (experiments/ab_inproc.py; round 2, under the graph's host cost, saw nothing).
+        constexpr bool fuse_ef_env = true;
         euler_finish_fused = fuse_ef_env && with_grads && !cfg.actor_layer_norm && !use_pec && !use_xchain && fused_euler && use_chain &&
                              fs > 1 && vp_tiles <= 32;
         if (use_xchain) emit_euler_xcd(pr);
