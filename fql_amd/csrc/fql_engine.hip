@@ -2473,7 +2473,9 @@ struct fql_engine {
         constexpr int bc_late_env = 0;
         const int bc_late = (lanes3 && with_grads) ? bc_late_env : 0;
         auto emit_bc = [&](int bc_lane) {
-            place("bcf", bc_lane, true);
+            // (three lanes: the BC flow's FORWARD on lane 1 in front of the one-step pass, its loss and backward stay on lane 2 - -0.5 .. -1.0 % per
+            // fp32 update in three in-process A/Bs under AQL dispatch, nothing in bf16x3; experiments/lane_sweep.sh)
+            place("bcf", lanes3 ? 1 : bc_lane, true);
             emit_forward(pr, p_bc, with_grads);
             place("bc", bc_lane, true);
             {
