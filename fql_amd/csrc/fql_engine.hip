@@ -298,6 +298,7 @@ struct fql_engine {
     int num_cus = 0;
     PassBuf p_os, p_os_bwd, p_bc, p_eu, p_c1[2], p_c2[2], p_ct[2];
     Program prog_fwdbwd, prog_opt, prog_loss;
+    Program prog_opt_split;   // the optimizer half with the critic's / BC flow's Adam on lane 1: fql_update_end_split issues that lane on the stream that carried bucket 0's all-reduce
     Program prog_full;   // single-GPU update in ONE graph: per-module Adam launches start as soon as that module's gradients exist
     int mod_chunk0[3] = {0, 0, 0}, mod_chunkn[3] = {0, 0, 0};  // chunk ranges of bc_flow, onestep, critic (leaf order)
     // data-parallel variant: the same update as three single-lane graphs (lane 0 before / after it needs lane 1, lane 1)
@@ -2654,6 +2655,10 @@ struct fql_engine {
             a.reads = {st};
             a.writes = {d_partials + mod_chunk0[m] * 4};
             if (m2 >= 0) { a.adam_c1 = mod_chunk0[m2]; a.adam_n1 = mod_chunkn[m2]; a.writes.push_back(d_partials + mod_chunk0[m2] * 4); }
+            if (m2 == -2) {   // all chunks (the modules' ranges tile [0, n_chunks))
+                a.adam_c0 = 0; a.adam_n = -1;
+                for (int mm = 0; mm < 3; ++mm) a.writes.push_back(d_partials + mod_chunk0[mm] * 4);
+            }
             // FQL_TAIL_MERGE (default on; =0 off): the critic's Adam, the first launch of lane 2's tail, also waits for the Euler target the actor-loss kernel behind it reads -
             // one launch with two cross-lane edges instead of two launches with one each (every such edge costs the waiting lane ~10 us)
             constexpr bool tail_merge = true;   // default on
@@ -2687,12 +2692,19 @@ struct fql_engine {
     // as in the fused program - critic and BC flow (gradient bucket 0) + the chain's weight-copy refresh on lane 1, the one-step
     // actor (bucket 1) and the bookkeeping on lane 0.  fql_update_end captures it as one two-lane graph; fql_update_end_split issues
     // lane 1 on the stream that carried bucket 0's all-reduce, so those Adam launches overlap lane 0's tail and bucket 1's reduce.
-    void build_opt_program(Program& pr) {
+    // fql_update_end runs it as ONE lane (a captured two-lane graph of five launches pays more for its fork and join than the two Adam launches
+    // overlap: the plain data-parallel step at world size 1, collective forced, 2167 -> 2298 updates/s).
+    void build_opt_program(Program& pr, bool two_lanes) {
         DevState* st = d_state;
-        adam_for(pr, 2, {NET_C0, NET_C1}, 1);
-        adam_for(pr, 0, {NET_BC}, 1);
-        if (use_chain) { emit_lane = 1; emit_wfrag(pr); }
-        adam_for(pr, 1, {NET_OS}, 0);
+        if (two_lanes) {
+            adam_for(pr, 2, {NET_C0, NET_C1}, 1);
+            adam_for(pr, 0, {NET_BC}, 1);
+            if (use_chain) { emit_lane = 1; emit_wfrag(pr); }
+            adam_for(pr, 1, {NET_OS}, 0);
+        } else {   // every chunk of every module in ONE Adam launch, then the copies' refresh, then the bookkeeping
+            adam_for(pr, 2, {NET_C0, NET_C1, NET_BC, NET_OS}, 0, -2);
+            if (use_chain) { emit_lane = 0; emit_wfrag(pr); }
+        }
         Op f{};
         f.type = OP_FINALIZE;
         f.fin_mode = 1;
@@ -2704,7 +2716,7 @@ struct fql_engine {
     }
     // the optimizer program as plain launches on two caller streams (no capture: five launches)
     void run_opt_split(hipStream_t s0, hipStream_t s1) {
-        Program& pr = prog_opt;
+        Program& pr = prog_opt_split;
         // lane 1 rewrites the critic's and the BC flow's parameters (and the chain's weight copies): it must not pass lane 0's last
         // reader of them, the Euler chain.  After a split begin that point is ev_c; otherwise everything enqueued on s0 so far.
         if (!ev_c) HIP_CHECK(hipEventCreateWithFlags(&ev_c, hipEventDisableTiming));
@@ -2783,6 +2795,7 @@ struct fql_engine {
     void free_workspace() {
         free_program(prog_fwdbwd);
         free_program(prog_opt);
+        free_program(prog_opt_split);
         free_program(prog_loss);
         free_program(prog_split);
         free_program(prog_full);
@@ -2910,10 +2923,11 @@ struct fql_engine {
         static const bool trace = getenv("FQL_TRACE") != nullptr;
 #define FQL_TR(msg) do { if (trace) fprintf(stderr, "[fql] %s\n", msg); } while (0)
         build_step_program(prog_fwdbwd, true);
-        build_opt_program(prog_opt);
+        build_opt_program(prog_opt, false);
+        build_opt_program(prog_opt_split, true);
         build_step_program(prog_loss, false);
         FQL_TR("programs built");
-        schedule(prog_fwdbwd, W); FQL_TR("scheduled fwdbwd"); schedule(prog_opt, W); schedule(prog_loss, W);
+        schedule(prog_fwdbwd, W); FQL_TR("scheduled fwdbwd"); schedule(prog_opt, W); schedule(prog_opt_split, W); schedule(prog_loss, W);
         FQL_TR("scheduled");
         capture(prog_fwdbwd); FQL_TR("captured fwdbwd"); capture(prog_opt); capture(prog_loss);
         FQL_TR("captured");
