@@ -1,6 +1,6 @@
 """A/B of two engine settings in ONE process: two agents, each created under its own environment (the engine reads its knobs when it builds
 its programs), timed in alternating fenced windows - process-to-process variance (+-2 %) drops out.
-usage: python experiments/ab_inproc.py "KEY=VAL ..." "KEY=VAL ..." [rounds] [updates per window] [precision]"""
+usage: python experiments/ab_inproc.py "KEY=VAL ..." "KEY=VAL ..." [rounds] [updates per window] [precision] [batch]"""
 import os
 import statistics
 import sys
@@ -14,7 +14,8 @@ envs = [dict(kv.split('=', 1) for kv in a.split()) if a.strip() and a.strip() !=
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 7
 n = int(sys.argv[4]) if len(sys.argv) > 4 else 300
 prec = sys.argv[5] if len(sys.argv) > 5 else 'fp32'
-B, H = 256, 512
+B = int(sys.argv[6]) if len(sys.argv) > 6 else 256
+H = 512
 cfg, ds, batch, noise = make_problem(29, 8, B, (H,) * 4, seed=3)
 cfg['precision'] = prec
 agents = []
