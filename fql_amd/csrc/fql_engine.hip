@@ -314,6 +314,7 @@ struct fql_engine {
     AqlProgram aql_full;
     std::vector<AqlDispatch>* aql_rec = nullptr;   // issue() records instead of launching while this is set
     bool last_update_aql = false;
+    bool aql_tried = false;                        // build_aql has run for the current programs (lazily: data-parallel and graph-only users never start the HSA side)
     bool hip_dirty = true;                         // HIP work may be pending on the engine's stream: drain it before the next AQL submit
     void aql_drain() {                             // every AQL update submitted so far has finished (host wait)
         if (!aql.up) return;
@@ -2937,8 +2938,7 @@ struct fql_engine {
             FQL_TR("scheduled full");
             capture(prog_full);
             FQL_TR("captured full");
-            build_aql(prog_full, aql_full);
-            FQL_TR(aql_full.ok ? "AQL packets built" : "AQL path off");
+            aql_tried = false;   // (the AQL form of this program is built by the first update that can use it: run_full)
         }
         {
             split_build = true;
@@ -3501,6 +3501,11 @@ static void run_program(fql_handle h, Program& pr, hipStream_t s) {
 // stream is drained first if HIP work may be pending on it).  Otherwise, or when that path is off: the captured graph on `s`.
 static void run_full(fql_handle h, hipStream_t s, bool own_stream) {
     static const int no_graph = getenv("FQL_NO_GRAPH") ? atoi(getenv("FQL_NO_GRAPH")) : 0;
+    if (own_stream && !no_graph && h->prog_full.exec && !h->aql_tried) {
+        h->aql_tried = true;
+        h->hip_touch();
+        h->build_aql(h->prog_full, h->aql_full);
+    }
     if (own_stream && h->aql_full.ok && !no_graph && h->prog_full.exec) {
         if (h->hip_dirty) { HIP_CHECK(hipStreamSynchronize(s)); h->hip_dirty = false; }
         try { h->aql.submit(h->aql_full); } catch (const AqlError& e) { throw HipError{e.msg}; }
