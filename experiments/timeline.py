@@ -16,7 +16,7 @@ from fql_amd import _cabi  # noqa: E402
 from fql_amd.synthetic import make_synthetic_dataset  # noqa: E402
 
 TYPES = ['gemm16', 'side', 'wgrad', 'lnbwd', 'prep', 'postos', 'euler_fin', 'pec', 'loss_critic', 'loss_q', 'loss_bc', 'loss_actor', 'conv_wprep',
-         'conv', 'conv_u8', 'pool', 'pool_bwd', 'conv_wgrad', 'conv_wred', 'enc_dz', 'chain', 'wfrag', 'adam', 'finalize']
+         'conv', 'conv_u8', 'pool', 'pool_bwd', 'conv_wgrad', 'conv_wred', 'enc_dz', 'chain', 'wfrag', 'xchain', 'adam', 'finalize']
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 od, ad, B = 29, 8, 256
 cfg = fql_amd.get_config()
@@ -42,13 +42,14 @@ for r in range(reps):
     # steady state, its launches enqueued while the previous update was still running.  Default: ONE update launched on an idle device.
     for _ in range(int(os.environ.get('FQL_TL_STEADY', '1'))):
         agent.update_from_dataset(B)
+    where = agent.synchronize()
     n = f(agent._h, 0, cap, lane, typ, grid, t0, t1, t2)
     assert n > 0, n
     cur = np.array([[t0[i], t1[i], t2[i]] for i in range(n)])
     acc = cur if acc is None else acc + cur
 acc /= reps
 order = np.argsort(acc[:, 0])
-print(f'# {n} launches, mean over {reps} updates; us since the first workgroup entry of the update')
+print(f'# {n} launches ({where} dispatch), mean over {reps} updates; us since the first workgroup entry of the update')
 print('# lane  op            wgs   first_entry  last_entry  last_exit   span')
 for i in order:
     if grid[i] == 0:
