@@ -2184,7 +2184,7 @@ struct fql_engine {
             if (!aql.up) throw AqlError{aql.why};
             std::vector<AqlDispatch> rec;
             aql_rec = &rec;
-            try { for (const Launch& L : pr.launches) issue(L, nullptr, -1); } catch (...) { aql_rec = nullptr; throw; }
+            try { for (const Launch& L : pr.launches) issue(L, nullptr, (&pr == &prog_full) ? (int)(&L - pr.launches.data()) : -1); } catch (...) { aql_rec = nullptr; throw; }   // (timeline ids: diagnostics build only)
             aql_rec = nullptr;
             const size_t n = pr.launches.size();
             if (rec.size() != n) throw AqlError{"a launch did not record exactly one dispatch"};
@@ -3972,13 +3972,31 @@ extern "C" int fql_debug_workspace(fql_handle h, int which, void* out, size_t by
 extern "C" int fql_debug_timeline(fql_handle h, int reset, int cap, int* lane, int* type, int* grid, double* t_first, double* t_last, double* t_exit) {
 #ifdef FQL_TIMELINE
     if (!h) return FQL_E_INVALID;
+    try { h->aql_drain(); } catch (...) { return FQL_E_HIP; }
     hipDeviceSynchronize();
     static std::vector<unsigned long long> host((size_t)FQL_TL_MAX * FQL_TL_WGS * 2);
+    // updates dispatched as AQL packets run the engine's OWN copy of the code object: its instance of the table, not the one HIP registered
+    void* aql_tab = nullptr;
+    if (h->aql.up && h->last_update_aql) {
+        hsa_executable_symbol_t sym;
+        if (hsa_executable_get_symbol_by_name(h->aql.exe, "g_fql_tl", &h->aql.agent, &sym) == HSA_STATUS_SUCCESS) {
+            uint64_t addr = 0;
+            if (hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_VARIABLE_ADDRESS, &addr) == HSA_STATUS_SUCCESS) aql_tab = (void*)(uintptr_t)addr;
+        }
+    }
     if (reset) {
         std::fill(host.begin(), host.end(), 0ull);
+        if (h->aql.up) {   // both instances
+            hsa_executable_symbol_t sym;
+            uint64_t addr = 0;
+            if (hsa_executable_get_symbol_by_name(h->aql.exe, "g_fql_tl", &h->aql.agent, &sym) == HSA_STATUS_SUCCESS &&
+                hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_VARIABLE_ADDRESS, &addr) == HSA_STATUS_SUCCESS && addr)
+                if (hipMemcpy((void*)(uintptr_t)addr, host.data(), host.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return FQL_E_HIP;
+        }
         return hipMemcpyToSymbol(HIP_SYMBOL(g_fql_tl), host.data(), host.size() * 8) == hipSuccess ? 0 : FQL_E_HIP;
     }
-    if (hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(g_fql_tl), host.size() * 8) != hipSuccess) return FQL_E_HIP;
+    if (aql_tab) { if (hipMemcpy(host.data(), aql_tab, host.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return FQL_E_HIP; }
+    else if (hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(g_fql_tl), host.size() * 8) != hipSuccess) return FQL_E_HIP;
     const int n = std::min<int>((int)h->prog_full.launches.size(), std::min(cap, FQL_TL_MAX));
     unsigned long long t0 = ~0ull;
     std::vector<unsigned long long> a(n, ~0ull), b(n, 0), c(n, 0);
