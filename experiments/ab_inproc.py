@@ -19,7 +19,13 @@ H = 512
 cfg, ds, batch, noise = make_problem(29, 8, B, (H,) * 4, seed=3)
 cfg['precision'] = prec
 agents = []
+from fql_amd import _cabi  # noqa: E402
 for e in envs:
+    lib = e.pop('LIB', None)          # LIB=<path>: this agent runs another build of the library (both live in the process)
+    if lib:
+        _cabi.LIB_PATH = os.path.abspath(lib)
+        _cabi._lib = None
+    e_show = dict(e, **({'LIB': lib} if lib else {}))
     for k, v in e.items():
         os.environ[k] = v
     a = fql_amd.FQLAgent.create(0, batch['observations'][:1], batch['actions'][:1], cfg)
@@ -30,6 +36,7 @@ for e in envs:
     agents.append(a)
     for k in e:
         del os.environ[k]
+    e.update(e_show)
 res = [[], []]
 for r in range(rounds):
     for i, a in enumerate(agents):

@@ -909,6 +909,22 @@ __device__ __forceinline__ void gemm64_body(const GemmTask& T, float* lds) {
     // staging coordinates: f = tid + 256 i -> row f / 16, float4 column f % 16 (2 RI float4 per thread for A, 4 for B)
     const int sr = tid >> 4, sc4 = tid & 15;
     constexpr int NRA = 2 * RI;
+    // two register sets: a chunk's loads stay in flight across two compute phases.  The loads carry NOTHING that waits for them (LayerNorm is applied
+    // when a chunk is written to LDS, as in the 32-row body), and the first two chunks are requested before the statistics' partial sums are folded.
+    f32x4 ra0[NRA], rb0[4], ra1[NRA], rb1[4], lg0, lb0, lg1, lb1;
+    lg0 = lb0 = lg1 = lb1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ Ag = T.A + (size_t)(row0 + sr) * T.lda + 4 * sc4;
+    const float* __restrict__ Bg = transb ? T.B + (size_t)(n0 + sr) * T.ldb + 4 * sc4 : T.B + (size_t)sr * T.ldb + n0 + 4 * sc4;
+    auto load_chunk = [&](f32x4 (&ra)[NRA], f32x4 (&rb)[4], f32x4& lg, f32x4& lb, int k0) {  // K is a multiple of 64: no guards, unconditional loads
+#pragma unroll
+        for (int i = 0; i < NRA; ++i) ra[i] = ldg4(Ag + (size_t)(16 * i) * T.lda + k0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[i] = transb ? ldg4(Bg + (size_t)(16 * i) * T.ldb + k0) : ldg4(Bg + (size_t)(k0 + 16 * i) * T.ldb);
+        if (a_ln) { lg = ldg4(T.ln_g + k0 + 4 * sc4); lb = ldg4(T.ln_b + k0 + 4 * sc4); }
+    };
+    const int nchunks = K >> 6;
+    load_chunk(ra0, rb0, lg0, lb0, 0);
+    if (nchunks > 1) load_chunk(ra1, rb1, lg1, lb1, 64);
     float mean[NRA], rstd[NRA];
 #pragma unroll
     for (int i = 0; i < NRA; ++i) { mean[i] = 0.f; rstd[i] = 1.f; }
@@ -926,31 +942,21 @@ __device__ __forceinline__ void gemm64_body(const GemmTask& T, float* lds) {
         }
     }
     GSTAMP();   // [1] LayerNorm statistics folded
-    f32x4 ra0[NRA], rb0[4], ra1[NRA], rb1[4];  // two register sets: a chunk's loads stay in flight across two compute phases
-    const float* __restrict__ Ag = T.A + (size_t)(row0 + sr) * T.lda + 4 * sc4;
-    const float* __restrict__ Bg = transb ? T.B + (size_t)(n0 + sr) * T.ldb + 4 * sc4 : T.B + (size_t)sr * T.ldb + n0 + 4 * sc4;
-    auto load_chunk = [&](f32x4 (&ra)[NRA], f32x4 (&rb)[4], int k0) {  // K is a multiple of 64: no guards, unconditional loads
-#pragma unroll
-        for (int i = 0; i < NRA; ++i) ra[i] = ldg4(Ag + (size_t)(16 * i) * T.lda + k0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rb[i] = transb ? ldg4(Bg + (size_t)(16 * i) * T.ldb + k0) : ldg4(Bg + (size_t)(k0 + 16 * i) * T.ldb);
-        if (a_ln) {
+    auto store_chunk = [&](f32x4 (&ra)[NRA], const f32x4 (&rb)[4], const f32x4& lg, const f32x4& lb, int k0, int buf) {
+        float* a = As + buf * TM * G64_S;
+        float* b = Bs + buf * 64 * G64_S;
+        if (a_ln) {   // utils/networks.py:58 on the rows of this chunk
             const int k = k0 + 4 * sc4;
-            const f32x4 g = ldg4(T.ln_g + k), be = ldg4(T.ln_b + k);
 #pragma unroll
             for (int i = 0; i < NRA; ++i) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float v = (ra[i][e] - mean[i]) * rstd[i] * g[e] + be[e];
+                    const float v = (ra[i][e] - mean[i]) * rstd[i] * lg[e] + lb[e];
                     ra[i][e] = (k + e < T.ln_width) ? v : 0.f;
                 }
                 if (ln_wr) stg4(T.ln_xout + (size_t)(row0 + sr + 16 * i) * T.lda + k, ra[i]);
             }
         }
-    };
-    auto store_chunk = [&](const f32x4 (&ra)[NRA], const f32x4 (&rb)[4], int buf) {
-        float* a = As + buf * TM * G64_S;
-        float* b = Bs + buf * 64 * G64_S;
 #pragma unroll
         for (int i = 0; i < NRA; ++i) *reinterpret_cast<f32x4*>(a + (sr + 16 * i) * G64_S + 4 * sc4) = ra[i];
 #pragma unroll
@@ -994,11 +1000,8 @@ __device__ __forceinline__ void gemm64_body(const GemmTask& T, float* lds) {
         }
     };
     // chunk ch computes from LDS slot ch & 1 while chunk ch+1 (set 0 / 1 alternating) and ch+2 are in flight
-    const int nchunks = K >> 6;
-    load_chunk(ra0, rb0, 0);
-    store_chunk(ra0, rb0, 0);
-    if (nchunks > 1) load_chunk(ra0, rb0, 64);
-    if (nchunks > 2) load_chunk(ra1, rb1, 128);
+    store_chunk(ra0, rb0, lg0, lb0, 0, 0);
+    if (nchunks > 2) load_chunk(ra0, rb0, lg0, lb0, 128);
     __syncthreads();
     GSTAMP();   // [2] first chunk staged (the stamp's wait also drains the two prefetched chunks: diagnostics only)
 #ifdef FQL_STAMPS  // diagnostic ablations (never in the product build): bit 15 = no streaming loads, bit 16 = no MFMAs
@@ -1007,15 +1010,16 @@ __device__ __forceinline__ void gemm64_body(const GemmTask& T, float* lds) {
     const bool dbg_noload = false, dbg_nocompute = false;
 #endif
     for (int ch = 0; ch < nchunks; ch += 2) {
+        // (register set 1 holds chunk ch + 1, set 0 chunk ch + 2 on entry)
         if (!dbg_nocompute) compute(0);
-        if (ch + 1 < nchunks) store_chunk(ra0, rb0, 1);
+        if (ch + 1 < nchunks) store_chunk(ra1, rb1, lg1, lb1, 64 * (ch + 1), 1);
         __syncthreads();
-        if (ch + 3 < nchunks && !dbg_noload) load_chunk(ra0, rb0, 64 * (ch + 3));
+        if (ch + 3 < nchunks && !dbg_noload) load_chunk(ra1, rb1, lg1, lb1, 64 * (ch + 3));
         if (ch + 1 < nchunks) {
             if (!dbg_nocompute) compute(1);
-            if (ch + 2 < nchunks) store_chunk(ra1, rb1, 0);
+            if (ch + 2 < nchunks) store_chunk(ra0, rb0, lg0, lb0, 64 * (ch + 2), 0);
             __syncthreads();
-            if (ch + 4 < nchunks && !dbg_noload) load_chunk(ra1, rb1, 64 * (ch + 4));
+            if (ch + 4 < nchunks && !dbg_noload) load_chunk(ra0, rb0, lg0, lb0, 64 * (ch + 4));
         }
     }
 
