@@ -94,3 +94,46 @@ def test_aql_can_be_switched_off():
     out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, FQL_AQL='0'), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert 'MODE graph' in out.stdout
+
+
+def test_aql_survives_batch_size_changes_balanced_sampling_and_teardown_with_updates_in_flight():
+    """The engine's queues across the calls that rebuild or retire its programs: a batch-size change (new workspace, new packets, same queues and signals),
+    balanced sampling (its own source descriptor), and an agent dropped while updates are still on the queues."""
+    import torch
+    import fql_amd
+    from fql_amd.datasets import Dataset, ReplayBuffer
+    od, ad = 13, 4
+    cfg, ds, batch, noise = make_problem(od, ad, 32, (64,) * 4, seed=31)
+    st = torch.cuda.Stream()
+    agents = []
+    for _ in range(2):
+        a = fql_amd.FQLAgent.create(2, batch['observations'][:1], batch['actions'][:1], cfg)
+        a.set_params(randomize_params(a.get_params(), 32))
+        train = Dataset.create(**{k: v.copy() for k, v in ds.items()})
+        train.attach(a)
+        rb = ReplayBuffer.create({k: v[0] for k, v in train.items()}, size=64).attach(a, replay=True)
+        rng = np.random.default_rng(33)
+        for _ in range(40):
+            rb.add_transition({'observations': rng.normal(size=od).astype(np.float32), 'actions': rng.uniform(-1, 1, size=ad).astype(np.float32),
+                               'rewards': np.float32(-1.0), 'masks': np.float32(1.0), 'terminals': np.float32(0.0),
+                               'next_observations': rng.normal(size=od).astype(np.float32)})
+        agents.append(a)
+    a, b = agents
+    kw = dict(stream=st.cuda_stream)
+    for B in (32, 64, 32):
+        for _ in range(7):
+            a.update_from_dataset(B)
+            b.update_from_dataset(B, **kw)
+        for _ in range(3):
+            a.update_balanced(B)
+            b.update_balanced(B, **kw)
+        assert a.synchronize() == 'aql' and b.synchronize() == 'graph'
+        st.synchronize()
+        assert a.read_info() == b.read_info()
+    _assert_same_state(a, b)
+    for _ in range(5):
+        a.update_from_dataset(32)          # still on the queues when the agent goes away: fql_destroy waits for them
+    del a, agents
+    import gc
+    gc.collect()
+    assert all(np.isfinite(v) for v in b.read_info().values())
