@@ -347,6 +347,57 @@ __device__ __forceinline__ void chain_body(const ChainArgs& P) {
     }
 #endif
 }
+// The one-step actor's head dgrad (agents/fql.py:62-79 through utils/networks.py:53-58) as a launch of its own on the critical lane, between the Euler
+// chain and the three tail dgrads: dX = (dA W_head^T) * GELU'(z_3) with dA = d(actor loss)/d(one-step actions) built in the prologue (GF_A_LOSSACT: distillation
+// term against the Euler target + the clip-masked Q gradient of both critic members; with GF_A_EULFIN the target is finished here from the last step's head
+// partials, same loads and summation order as fql_euler_finish_kernel).  The contraction is 16 wide - four MFMAs a wave - so the launch is its loads: the task
+// arrives as the kernel argument (no table hop), one thread builds one dA element, a wave owns a 16 x 16 output tile.  It replaces the generic 16-row kernel's
+// instantiation for this task (216 registers and 192 spilled scalars there: every other flag combination's state was live through it).
+__global__ __launch_bounds__(FQL_THREADS) void fql_head_dgrad_kernel(const GemmTask T) {
+    __shared__ __attribute__((aligned(16))) float da[16 * 20];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, q = lane >> 4;
+    const int ntn = T.N >> 6;
+    const int tm = (int)blockIdx.x / ntn, tn = (int)blockIdx.x - tm * ntn;
+    const int row0 = tm * 16, n0 = tn * 64 + 16 * wave;
+    // what depends on nothing of this launch: the wave's slice of the head kernel (row-major [N][ap]: lane (c, q) reads W[n0 + c][4q .. 4q + 3]) and GELU'(z)
+    const f32x4 b4 = ldg4(T.B + (size_t)(n0 + c) * T.ldb + 4 * q);
+    float zp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) zp[i] = ldg(T.Zprev + (size_t)(row0 + 4 * q + i) * T.ldc + n0 + c);
+    {
+        const int r = tid >> 4, j = tid & 15;
+        float g = 0.f;
+        if (j < T.i2) {
+            const float ar = ldg(T.ea_in + (size_t)(row0 + r) * T.i0 + j);
+            float tg;
+            if (T.flags & GF_A_EULFIN) {
+                float pv[32];
+#pragma unroll
+                for (int tp = 0; tp < 32; ++tp) pv[tp] = ldg(T.aux2 + ((size_t)min(tp, T.ln_width - 1) * T.M + row0 + r) * T.i0 + j);
+                float sum = 0.f;
+#pragma unroll
+                for (int tp = 0; tp < 32; ++tp) sum += (tp < T.ln_width) ? pv[tp] : 0.f;
+                tg = clip1(ldg(T.aux + (size_t)(row0 + r) * T.i0 + j) + (sum + ldg(T.eb + j)) * T.f1);
+                if (tn == 0) stg(const_cast<float*>(T.evp) + (size_t)(row0 + r) * T.i0 + j, tg);   // the actor-loss metrics read it
+            } else tg = ldg(T.evp + (size_t)(row0 + r) * T.i0 + j);
+            g = T.f0 * (ar - tg);
+            if (ar > -1.0f && ar < 1.0f) {
+                const size_t o = (size_t)(row0 + r) * T.e_ntp + T.i1 + j;
+                g += ldg(T.ew + o) + ldg(T.ew4 + o);
+            }
+            if (tn == 0 && T.ea_out) stg(T.ea_out + (size_t)(row0 + r) * T.i0 + j, g);   // the head's weight gradient reads it
+        }
+        da[r * 20 + j] = g;
+    }
+    __syncthreads();
+    const f32x4 a4 = *reinterpret_cast<const f32x4*>(&da[c * 20 + 4 * q]);   // dA[row c][k = 4q + s]
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s4], b4[s4], acc, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stg(T.C + (size_t)(row0 + 4 * q + i) * T.ldc + n0 + c, acc[i] * zp[i]);
+}
+
 template <int H, int V>
 __global__ __launch_bounds__(FQL_CHAIN_THREADS, FQL_CHAIN_WAVES) void fql_chain_kernel(const ChainArgs P) { chain_body<H, V>(P); }
 // two independent tasks of one variant in one launch (blockIdx.y picks the task): the two ensemble members of the critic's Q-gradient chain

@@ -124,7 +124,7 @@ struct Leaf {
 // program = ordered ops with read/write sets -> levels -> launches
 // ------------------------------------------------------------------------------------------------
 enum OpType { OP_GEMM, OP_GEMM64, OP_WGRAD, OP_LNBWD, OP_PREP, OP_POSTOS, OP_EULER_FIN, OP_PEC, OP_LOSS_CRITIC, OP_LOSS_Q, OP_LOSS_BC,
-              OP_LOSS_ACTOR, OP_CONV_WPREP, OP_CONV, OP_CONV_U8, OP_POOL, OP_POOL_BWD, OP_CONV_WGRAD, OP_CONV_WRED, OP_ENC_DZ, OP_CHAIN, OP_WFRAG, OP_XCHAIN, OP_ADAM,
+              OP_LOSS_ACTOR, OP_CONV_WPREP, OP_CONV, OP_CONV_U8, OP_POOL, OP_POOL_BWD, OP_CONV_WGRAD, OP_CONV_WRED, OP_ENC_DZ, OP_CHAIN, OP_WFRAG, OP_XCHAIN, OP_HEAD_DGRAD, OP_ADAM,
               OP_FINALIZE };
 
 struct Op {
@@ -1784,7 +1784,7 @@ struct fql_engine {
             const int li = launch_of[oi];
             if (li < 0) continue;
             double m = 0.0;
-            if (o.type == OP_GEMM || o.type == OP_GEMM64) m = (double)o.gemm.M * o.gemm.N * o.gemm.K;
+            if (o.type == OP_GEMM || o.type == OP_GEMM64 || o.type == OP_HEAD_DGRAD) m = (double)o.gemm.M * o.gemm.N * o.gemm.K;
             else if (o.type == OP_WGRAD) m = (double)o.wgrad.M * o.wgrad.Kin * o.wgrad.N;
             else if (o.type == OP_CHAIN) {
                 const double H = cfg.actor_hidden[0];
@@ -2003,6 +2003,9 @@ struct fql_engine {
             }
             case OP_WFRAG:
                 FQL_LAUNCH(fql_wfrag_kernel, dim3(wfrag_grid), dim3(FQL_THREADS), 0, s, (const WfragTask*)d_wfrag, wfrag_n, tl);
+                break;
+            case OP_HEAD_DGRAD:
+                FQL_LAUNCH(fql_head_dgrad_kernel, dim3((L.op.gemm.M / 16) * (L.op.gemm.N / 64)), dim3(FQL_THREADS), 0, s, L.op.gemm);
                 break;
             case OP_XCHAIN:   // one workgroup per CU: 8 XCDs x 32 members
                 FQL_LAUNCH(fql_xchain_kernel, dim3(XCH_NGRP * XCH_NMEM), dim3(256), x_lds, s, L.op.xchain);
@@ -2598,6 +2601,10 @@ struct fql_engine {
                 t.ea_in = p_os.out + (size_t)B * ap; t.evp = tgt; t.i0 = ap; t.i1 = od; t.i2 = ad;
                 t.ew = p_c2[0].dx0; t.ew4 = p_c2[1].dx0; t.e_ntp = inp_c;
                 t.ea_out = da;
+                // the dedicated launch (fql_head_dgrad_kernel) where the task has its shape: a 16-wide contraction into multiples of 64 columns
+                if (t.K == 16 && t.N % 64 == 0 && t.M % 16 == 0 && (t.flags & GF_TRANS_B) && (t.flags & GF_GELUGRAD) && !(t.flags & (GF_BIAS | GF_RELUGRAD | GF_A_LN)) &&
+                    cfg.precision != 1)
+                    d.type = OP_HEAD_DGRAD;
                 t.f0 = cfg.alpha * 2.0f / (float)(B * ad);
                 d.reads.erase(std::remove(d.reads.begin(), d.reads.end(), (const void*)da), d.reads.end());
                 for (const void* r : {(const void*)p_os.out, (const void*)tgt, (const void*)p_c2[0].dx0, (const void*)p_c2[1].dx0}) d.reads.push_back(r);
