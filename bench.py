@@ -44,7 +44,7 @@ OP_NAMES = ['fql_gemm16_kernel', 'fql_side_kernel', 'fql_wgrad_kernel', 'fql_lnb
             'fql_euler_finish_kernel', 'fql_euler_persistent_kernel', 'fql_loss_critic_kernel', 'fql_loss_q_kernel', 'fql_loss_bc_kernel',
             'fql_loss_actor_kernel', 'fql_conv_wprep_kernel', 'fql_conv3x3_kernel', 'fql_conv3x3_u8_kernel', 'fql_maxpool_kernel',
             'fql_maxpool_bwd_kernel', 'fql_conv_wgrad_kernel', 'fql_conv_wgrad_reduce_kernel', 'fql_enc_dz_kernel', 'fql_chain_kernel',
-            'fql_wfrag_kernel', 'fql_xchain_kernel', 'fql_head_dgrad_kernel', 'fql_adam_kernel', 'fql_finalize_kernel']
+            'fql_wfrag_kernel', 'fql_xchain_kernel', 'fql_head_dgrad_kernel', 'fql_dgrad0_kernel', 'fql_adam_kernel', 'fql_finalize_kernel']
 
 
 def cpu_baseline(cfg, od, ad, B, budget_s=18.0, img=None):

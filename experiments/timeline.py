@@ -16,7 +16,7 @@ from fql_amd import _cabi  # noqa: E402
 from fql_amd.synthetic import make_synthetic_dataset  # noqa: E402
 
 TYPES = ['gemm16', 'side', 'wgrad', 'lnbwd', 'prep', 'postos', 'euler_fin', 'pec', 'loss_critic', 'loss_q', 'loss_bc', 'loss_actor', 'conv_wprep',
-         'conv', 'conv_u8', 'pool', 'pool_bwd', 'conv_wgrad', 'conv_wred', 'enc_dz', 'chain', 'wfrag', 'xchain', 'head_dgrad', 'adam', 'finalize']
+         'conv', 'conv_u8', 'pool', 'pool_bwd', 'conv_wgrad', 'conv_wred', 'enc_dz', 'chain', 'wfrag', 'xchain', 'head_dgrad', 'dgrad0', 'adam', 'finalize']
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 od, ad, B = 29, 8, 256
 cfg = fql_amd.get_config()

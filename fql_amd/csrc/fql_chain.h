@@ -347,6 +347,46 @@ __device__ __forceinline__ void chain_body(const ChainArgs& P) {
     }
 #endif
 }
+// dQ/da of the critic members (agents/fql.py:69-72 through utils/networks.py:53-58): the input gradient of the critic's first layer, of which a state agent
+// needs nothing but the ACTION block - 16 columns of dX0 = dZ0 W0^T starting at `col0` (the observation part feeds nobody: no encoder behind it).  It is the
+// last launch of the Q-gradient lane and what the critical lane's tail waits for.  The generic 16-row kernel computed all 64 input columns with 216 registers
+// a lane (so it could not sit beside the side lanes' workgroups and took 11-15 us in the steady state); here: up to four tasks as the kernel argument, one
+// workgroup per task and 16-row tile, the four waves split the contraction, every operand of a wave is eight 16-byte loads of one kernel row / one dZ row.
+struct Dgrad0Args {
+    GemmTask t[4];
+    int ntasks, col0;
+};
+__global__ __launch_bounds__(FQL_THREADS) void fql_dgrad0_kernel(const Dgrad0Args P) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 64 * 4];
+    const int tid = threadIdx.x, kp = tid >> 6, lane = tid & 63, c = lane & 15, q = lane >> 4;
+    const int ntm = P.t[0].M >> 4;
+    const int ti = (int)blockIdx.x / ntm, tm = (int)blockIdx.x - ti * ntm;
+    const GemmTask& T = P.t[ti];
+    const int row0 = tm * 16, kq = T.K >> 2;           // contraction columns per wave (a multiple of 16)
+    const float* ap = T.A + (size_t)(row0 + c) * T.lda + kp * kq + 4 * q;          // dZ0[row c][k]
+    const float* bp = T.B + (size_t)(P.col0 + c) * T.ldb + kp * kq + 4 * q;        // W0[input col0 + c][k] (row-major [in][out]: contiguous in k)
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+    for (int g0 = 0; g0 < kq; g0 += 128) {             // (K is a multiple of 512.)  8 k-groups of 16 per round: 16 loads in flight, then 32 MFMAs on two accumulator chains
+        f32x4 a[8], b[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { a[g] = ldg4(ap + g0 + 16 * g); b[g] = ldg4(bp + g0 + 16 * g); }
+#pragma unroll
+        for (int g = 0; g < 8; g += 2)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][s4], b[g][s4], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g + 1][s4], b[g + 1][s4], acc2, 0, 0, 0);
+            }
+    }
+    acc += acc2;
+    *reinterpret_cast<f32x4*>(&red[(kp * 64 + lane) * 4]) = acc;
+    __syncthreads();
+    float v = 0.f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) v += red[(p * 64 + lane) * 4 + kp];      // wave kp finishes row 4q + kp, column c
+    stg(T.C + (size_t)(row0 + 4 * q + kp) * T.ldc + P.col0 + c, v);
+}
+
 // The one-step actor's head dgrad (agents/fql.py:62-79 through utils/networks.py:53-58) as a launch of its own on the critical lane, between the Euler
 // chain and the three tail dgrads: dX = (dA W_head^T) * GELU'(z_3) with dA = d(actor loss)/d(one-step actions) built in the prologue (GF_A_LOSSACT: distillation
 // term against the Euler target + the clip-masked Q gradient of both critic members; with GF_A_EULFIN the target is finished here from the last step's head

@@ -124,7 +124,7 @@ struct Leaf {
 // program = ordered ops with read/write sets -> levels -> launches
 // ------------------------------------------------------------------------------------------------
 enum OpType { OP_GEMM, OP_GEMM64, OP_WGRAD, OP_LNBWD, OP_PREP, OP_POSTOS, OP_EULER_FIN, OP_PEC, OP_LOSS_CRITIC, OP_LOSS_Q, OP_LOSS_BC,
-              OP_LOSS_ACTOR, OP_CONV_WPREP, OP_CONV, OP_CONV_U8, OP_POOL, OP_POOL_BWD, OP_CONV_WGRAD, OP_CONV_WRED, OP_ENC_DZ, OP_CHAIN, OP_WFRAG, OP_XCHAIN, OP_HEAD_DGRAD, OP_ADAM,
+              OP_LOSS_ACTOR, OP_CONV_WPREP, OP_CONV, OP_CONV_U8, OP_POOL, OP_POOL_BWD, OP_CONV_WGRAD, OP_CONV_WRED, OP_ENC_DZ, OP_CHAIN, OP_WFRAG, OP_XCHAIN, OP_HEAD_DGRAD, OP_DGRAD0, OP_ADAM,
               OP_FINALIZE };
 
 struct Op {
@@ -173,6 +173,7 @@ struct Launch {
     bool side = false;           // merged gemm64 + wgrad + lnbwd launch
     void *table_w = nullptr, *table_l = nullptr, *table_m = nullptr;
     int n_w = 0, n_l = 0, tile_w = 0, tile_l = 0, tile_m = 0;
+    std::vector<GemmTask> dg_tasks;   // OP_DGRAD0: the (<= 4) tasks of this launch, handed over as the kernel argument
     std::vector<int> waits;      // launches of the OTHER lane that must have completed
     bool record_after = false;   // some launch of the other lane waits on this one
     hipEvent_t ev = nullptr;
@@ -1346,6 +1347,11 @@ struct fql_engine {
             if (l == 0) {
                 t.C = p.dx0;
                 op.writes = {t.C};
+                // state agents read nothing of dX0 but the action block (dQ/da; no encoder behind the observations): the lean 16-column launch
+                if (!visual && cfg.precision != 1 && t.K % 512 == 0 && t.M % 16 == 0 && cfg.obs_dim + 16 <= t.N && cfg.act_dim <= 16) {
+                    op.type = OP_DGRAD0;
+                    t.i1 = cfg.obs_dim;
+                }
                 push(pr, op);
                 break;
             }
@@ -1657,6 +1663,21 @@ struct fql_engine {
                     pr.launches.push_back(L);
                     continue;
                 }
+                if (ty == OP_DGRAD0 && !sel.empty()) {   // the members' tasks of a level in launches of up to four (the kernel takes them as its argument)
+                    for (size_t i0 = 0; i0 < sel.size(); i0 += 4) {
+                        Launch L;
+                        L.type = OP_DGRAD0;
+                        L.op = *sel[i0];
+                        L.lane = lane;
+                        for (size_t i = i0; i < std::min(sel.size(), i0 + 4); ++i) {
+                            if (sel[i]->gemm.M != sel[i0]->gemm.M || sel[i]->gemm.i1 != sel[i0]->gemm.i1) invalid("internal: dQ/da tasks of one level differ in shape");
+                            L.dg_tasks.push_back(sel[i]->gemm);
+                            launch_of[sel[i] - pr.ops.data()] = (int)pr.launches.size();
+                        }
+                        pr.launches.push_back(L);
+                    }
+                    continue;
+                }
                 if (ty == OP_CONV_WPREP && sel.size() > 1) {   // the encoder passes of one level refresh their LDS-layout weight copies in ONE launch
                     int tot = 0;
                     for (const Op* o : sel) tot += o->wprep_n;
@@ -1785,6 +1806,7 @@ struct fql_engine {
             if (li < 0) continue;
             double m = 0.0;
             if (o.type == OP_GEMM || o.type == OP_GEMM64 || o.type == OP_HEAD_DGRAD) m = (double)o.gemm.M * o.gemm.N * o.gemm.K;
+            else if (o.type == OP_DGRAD0) m = (double)o.gemm.M * 16.0 * o.gemm.K;
             else if (o.type == OP_WGRAD) m = (double)o.wgrad.M * o.wgrad.Kin * o.wgrad.N;
             else if (o.type == OP_CHAIN) {
                 const double H = cfg.actor_hidden[0];
@@ -2004,6 +2026,13 @@ struct fql_engine {
             case OP_WFRAG:
                 FQL_LAUNCH(fql_wfrag_kernel, dim3(wfrag_grid), dim3(FQL_THREADS), 0, s, (const WfragTask*)d_wfrag, wfrag_n, tl);
                 break;
+            case OP_DGRAD0: {
+                Dgrad0Args a{};
+                a.ntasks = (int)L.dg_tasks.size(); a.col0 = L.op.gemm.i1;
+                for (int i = 0; i < a.ntasks; ++i) a.t[i] = L.dg_tasks[i];
+                FQL_LAUNCH(fql_dgrad0_kernel, dim3(a.ntasks * (L.op.gemm.M / 16)), dim3(FQL_THREADS), 0, s, a);
+                break;
+            }
             case OP_HEAD_DGRAD:
                 FQL_LAUNCH(fql_head_dgrad_kernel, dim3((L.op.gemm.M / 16) * (L.op.gemm.N / 64)), dim3(FQL_THREADS), 0, s, L.op.gemm);
                 break;
